@@ -1,0 +1,233 @@
+/*
+ * pba.h -- C ABI of the MI355X seed-and-extend overlap engine (libpba.so).
+ *
+ * This is the drop-in boundary.  The reference (vmingchen/PacBioAssembly) has no
+ * FFI layer: its mains and tests compile against the header-level C++ API in
+ * src/dna_seq.h, src/seq_aligner.h and src/ref_seq.h.  include/compat/ re-creates
+ * that API (same class, method and field names) on top of the entry points below;
+ * each entry point names the reference interface it replaces (file:line into
+ * /root/reference/).  Plain pointers and sizes only; no exceptions cross the
+ * boundary; every function that can fail returns a pba_status.
+ *
+ * Threading: a pba_ctx is bound to one GPU and one HIP stream and must be used by
+ * one host thread at a time (the reference is single-threaded with global
+ * singletons, spaced_seed.cpp:71-96).  One process per GPU, one ctx per process.
+ *
+ * There is no CPU fallback: with no usable GPU pba_ctx_create fails with
+ * PBA_E_NODEVICE and nothing else in the device API can be called.
+ */
+#ifndef PBA_H
+#define PBA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBA_VERSION 1
+
+typedef enum {
+    PBA_OK = 0,
+    PBA_E_INVALID = -1,     /* bad argument */
+    PBA_E_NOMEM = -2,       /* host or device allocation failed */
+    PBA_E_HIP = -3,         /* a HIP call or kernel failed; see pba_ctx_error */
+    PBA_E_TOOLONG = -4,     /* sequence longer than the engine supports */
+    PBA_E_NODEVICE = -5,    /* no usable gfx950 device */
+    PBA_E_ALPHABET = -6     /* byte outside ACGT where the packed path needs ACGT */
+} pba_status;
+
+/* ------------------------------------------------------------------------ */
+/* Host-side codec.  Pure functions, no ctx, bit-compatible with dna_seq.   */
+/* ------------------------------------------------------------------------ */
+
+/* dna_seq::encode (dna_seq.h:86): 16 chars -> u32, byte k = bases 4k..4k+3 */
+uint32_t pba_encode16(const char *text16);
+/* dna_seq::decode (dna_seq.h:101) */
+void pba_decode16(uint32_t code, char *text16);
+/* dna_seq::text2bin (dna_seq.h:113) with an explicit length: writes the record
+ * [u32 len][ceil(len/4) packed bytes]; returns bytes written, 0 if cap is too small */
+size_t pba_text2bin(const char *text, size_t tlen, uint8_t *record, size_t cap);
+/* dna_seq::bin2text (dna_seq.h:133): returns the length, writes the NUL; 0 if cap <= len */
+size_t pba_bin2text(const uint8_t *record, char *text, size_t cap);
+/* dna_seq::seed_at (dna_seq.h:62), BUG-COMPATIBLE: for pos%4==0 it returns the word at
+ * byte offset pos, exactly like the reference */
+uint32_t pba_seed_at(const uint8_t *record, int pos);
+/* the window seed_at was meant to return: == pba_encode16(text + pos) */
+uint32_t pba_seed_at_fixed(const uint8_t *record, int pos);
+/* parse_pattern (spaced_seed.cpp:167) / locator.cpp:51-54: '1' -> care, else don't care */
+uint32_t pba_mask_from_pattern(const char *pattern);
+/* dna_seq::value_at (dna_seq.h:78) */
+char pba_value_at(uint8_t packed_byte, int idx);
+/* record walk of open_binary (spaced_seed.cpp:330-342): byte offsets of the records with
+ * min_excl < len < max_excl; returns how many were kept (writes at most cap offsets) */
+size_t pba_open_binary(const uint8_t *file, size_t file_len, uint32_t min_excl, uint32_t max_excl,
+                       uint64_t *offsets, size_t cap, size_t *n_records_total);
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic workload generator (bench/test infrastructure, host code).     */
+/* Integer-only counter RNG: the same bytes on every machine.               */
+/* ------------------------------------------------------------------------ */
+void pba_synth_genome(uint64_t seed, char *out, size_t n);
+/* n_reads reads of read_len bases, forward strand, start uniform in [0, L - 1.5*read_len),
+ * per-step error p_ins / p_del / p_sub.  out holds n_reads*read_len chars
+ * (no separators); starts (nullable) receives each read's genome start. */
+int pba_synth_reads(uint64_t seed, const char *genome, size_t L, uint32_t n_reads, uint32_t read_len,
+                    double p_ins, double p_del, double p_sub, char *out, uint32_t *starts, int nthreads);
+
+/* ------------------------------------------------------------------------ */
+/* Context                                                                  */
+/* ------------------------------------------------------------------------ */
+typedef struct pba_ctx pba_ctx;
+int pba_ctx_create(int device_id, pba_ctx **ctx);
+void pba_ctx_destroy(pba_ctx *ctx);
+/* text of the last failure on this ctx (never NULL) */
+const char *pba_ctx_error(const pba_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own */
+int pba_ctx_set_stream(pba_ctx *ctx, void *hip_stream);
+int pba_ctx_sync(pba_ctx *ctx);
+/* device facts for the bench report */
+int pba_ctx_device_info(const pba_ctx *ctx, char *name, size_t name_cap, int *n_cu, int *clock_mhz,
+                        uint64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------ */
+/* Sequence sets resident in HBM, 2-bit packed in the reference byte layout */
+/* (dna_seq.h:147-159: first base in bits 7:6), each sequence 16-B aligned. */
+/* Replaces: the mmap'd read buffer (spaced_seed.cpp:310-345), contig[] and */
+/* sequence[] (locator.cpp:26-27), ref_seq::txt_buf (ref_seq.h:370).        */
+/* ------------------------------------------------------------------------ */
+typedef struct pba_seqs pba_seqs;
+/* text: concatenated ASCII; sequence i = text[offsets[i] .. offsets[i+1]).  Bytes are packed
+ * with C2I (dna_seq.h:21).  If strict_acgt != 0 a byte outside "ACGT" fails with
+ * PBA_E_ALPHABET (the packed DP compares codes, the reference compares bytes: they agree
+ * exactly on ACGT input).  Packing runs on the GPU. */
+int pba_seqs_from_text(pba_ctx *ctx, const char *text, const uint64_t *offsets, uint32_t n,
+                       int strict_acgt, pba_seqs **out);
+/* same, but text/offsets are DEVICE pointers (inputs already resident in HBM) */
+int pba_seqs_from_device_text(pba_ctx *ctx, const void *d_text, const void *d_offsets_u64, uint32_t n,
+                              uint64_t total_bytes, uint32_t max_len, pba_seqs **out);
+/* reference binary read file ([u32 len][packed])*, kept records min_excl < len < max_excl
+ * (spaced_seed.cpp:330-342); payloads are uploaded as they are, no re-packing */
+int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, uint32_t min_excl,
+                          uint32_t max_excl, pba_seqs **out);
+void pba_seqs_destroy(pba_seqs *s);
+uint32_t pba_seqs_count(const pba_seqs *s);
+uint32_t pba_seqs_max_len(const pba_seqs *s);
+uint64_t pba_seqs_packed_bytes(const pba_seqs *s);
+int pba_seqs_lengths(const pba_seqs *s, uint32_t *lengths, uint32_t cap);
+/* unpack sequence i back to text (bin2text), for round-trip checks */
+int pba_seqs_get_text(pba_ctx *ctx, const pba_seqs *s, uint32_t i, char *text, size_t cap);
+
+/* ------------------------------------------------------------------------ */
+/* Seed-hit index.  Replaces hash_table = hash_map<unsigned, list<int>>     */
+/* (common.h:54) and its two builders.                                      */
+/* ------------------------------------------------------------------------ */
+typedef struct pba_index pba_index;
+typedef enum {
+    PBA_INDEX_ALL = 0,        /* locator.cpp:62-66: every position [0,len), tail windows padded with code 3 */
+    PBA_INDEX_HEAD_TAIL = 1   /* ref_seq::get_seedmap, ref_seq.h:291-311: head ascending, then tail descending */
+} pba_index_mode;
+/* index sequence `seq` of `target` under `mask`; entries whose masked key is 0 are dropped
+ * (ref_seq.h:300,307; locator.cpp:64); per-key hit order = the reference's insertion order */
+int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode,
+                    pba_index **out);
+void pba_index_destroy(pba_index *ix);
+uint64_t pba_index_entries(const pba_index *ix);
+/* what get_seedmap returns (ref_seq.h:310): positions visited, not entries kept */
+uint32_t pba_index_visited(const pba_index *ix);
+/* all entries sorted by key, reference hit order within a key; returns PBA_OK and *n */
+int pba_index_dump(pba_ctx *ctx, const pba_index *ix, uint32_t *keys, int32_t *pos, uint64_t cap, uint64_t *n);
+/* hash_table::find (locator.cpp:76, spaced_seed.cpp:265) for a batch of keys: for key q the hits are
+ * hit_pos[hit_off[q] .. hit_off[q+1]) in reference list order.  hit_off has n_keys+1 slots. */
+int pba_index_find(pba_ctx *ctx, const pba_index *ix, const uint32_t *keys, uint32_t n_keys,
+                   uint64_t *hit_off, int32_t *hit_pos, uint64_t hit_cap);
+
+/* ------------------------------------------------------------------------ */
+/* Banded edit-distance extension.  Replaces seq_aligner<MAXN,MAXM>::align  */
+/* (seq_aligner.h:92-125) and its result fields (seq_aligner.h:73-81).      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t a_seq;      /* sequence id in set A */
+    int32_t  a_pos;      /* accessor origin: base index inside the sequence (dna_seq.h:191) */
+    int32_t  a_len;      /* accessor length */
+    uint32_t b_seq;
+    int32_t  b_pos;
+    int32_t  b_len;
+    uint32_t flags;      /* PBA_A_BACKWARD / PBA_B_BACKWARD: element k is seq[pos-k] (dna_seq.h:211,221) */
+} pba_pair;
+#define PBA_A_BACKWARD 1u
+#define PBA_B_BACKWARD 2u
+
+typedef struct {
+    int32_t rc;          /* align()'s return: -1 or matlen_b (seq_aligner.h:106,111,114,124) */
+    int32_t cost;        /* final_cost() (seq_aligner.h:130); 0 when rc < 0 */
+    int32_t matlen_a;    /* 0 when rc < 0 unless only the acceptance test failed */
+    int32_t matlen_b;
+    int32_t len_a;       /* parameter block, seq_aligner.h:94-102 */
+    int32_t len_b;
+    int32_t max_dst;
+} pba_result;
+
+typedef enum {
+    PBA_KERNEL_AUTO = 0,
+    PBA_KERNEL_ROWSWEEP = 1,   /* full-band row sweep, band row in LDS */
+    PBA_KERNEL_BITVEC = 2      /* bit-parallel delta encoding, exact */
+} pba_kernel;
+
+/* maxn/maxm: the template limits of the seq_aligner instantiation being replaced (size guard,
+ * seq_aligner.h:104: len_a >= maxn+maxm || max_dst >= maxm -> -1); maxn <= 0 disables the guard */
+int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n,
+                    double R, int maxn, int maxm, int kernel, pba_result *out);
+/* one pair given as host text, RAW BYTE comparison exactly like seq_aligner.h:136 (any bytes,
+ * case-sensitive).  a/b are accessor origins: element k is p[k] when fwd, p[-k] otherwise. */
+int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int a_len, const char *b, int b_fwd, int b_len,
+                   double R, int maxn, int maxm, pba_result *out);
+
+/* ------------------------------------------------------------------------ */
+/* Drivers: the reference's ordered first-success loops, run on the GPU.    */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t read;        /* index into the read set */
+    int32_t nseq;        /* locator's id: index among reads with len >= min_len, else -1 (locator.cpp:72,91) */
+    int32_t found;
+    int32_t j;           /* probe offset of the successful candidate, -1 if none */
+    int32_t pos;         /* TSV column 2 (locator.cpp:84) */
+    int32_t cost;        /* TSV column 3 */
+    int32_t seglen;      /* TSV column 4: len - j */
+    int32_t matlen_a, matlen_b;
+    int32_t n_pairs;     /* candidate pairs the reference loop hands to align for this read */
+} pba_loc_row;
+
+typedef struct {
+    int64_t n_reads_kept, n_probe_hits, n_pairs, n_located;
+    int64_t n_cells;     /* band cells the reference loop would evaluate for those pairs */
+} pba_loc_stats;
+
+/* locator.cpp:70-92 with R / trials / min_len as parameters (stock: 0.15 / 50 / 500).
+ * ix must be a PBA_INDEX_ALL index of sequence target_seq of `target`. */
+int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32_t target_seq,
+               const pba_seqs *reads, double R, int trials, int min_len, int maxn, int maxm, int kernel,
+               pba_loc_row *rows, pba_loc_stats *stats);
+
+typedef struct {
+    int32_t read, found, j, dir;   /* dir +1 forward / -1 backward (spaced_seed.cpp:426) */
+    int32_t ref_pos;               /* hit position (list value) */
+    int32_t cost, matlen_a, matlen_b;
+    int32_t n_trials;              /* probes that hit the map (DBG _ntrials, spaced_seed.cpp:268-270) */
+    int32_t n_pairs;
+} pba_ss_row;
+
+/* one locked round of spaced_seed.cpp:420-437 against a PBA_INDEX_HEAD_TAIL index.
+ * buggy_seed_at != 0 reproduces dna_seq::seed_at's pos%4==0 behaviour (needs reads built with
+ * pba_seqs_from_records so the bytes after each record are the file's). */
+int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq,
+                     const pba_seqs *reads, double R, int max_trial, int overlap_min, int buggy_seed_at,
+                     int kernel, pba_ss_row *rows);
+
+const char *pba_strerror(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

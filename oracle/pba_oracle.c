@@ -1,0 +1,614 @@
+/*
+ * pba_oracle.c -- CPU restatement of the reference seed-and-extend path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see pba_oracle.h).  Plain C, scalar, and on purpose
+ * "faithful": node-based hash map with per-key position lists, full-band row
+ * sweep storing 8 bytes per DP cell, first-success driver loops -- so that the
+ * time it takes is an honest stand-in for the reference CPU path when bench.py
+ * times it next to the GPU.  Parity status: PINNED (header comment).
+ *
+ * All file:line citations are into /root/reference/.
+ */
+#include "pba_oracle.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================== */
+/* codec                                                                    */
+/* ======================================================================== */
+
+/* dna_seq.h:21 -- A,C,G map to 0,1,2; every other byte (T, N, lowercase, NUL, '\n') to 3 */
+int orc_c2i(int ch)
+{
+    switch (ch) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    default:  return 3;
+    }
+}
+
+static const char ORC_I2C[4] = { 'A', 'C', 'G', 'T' };   /* dna_seq.h:30 */
+
+/* dna_seq.h:147-159 -- first base in bits 7:6; a short tail is zero-padded low */
+static uint8_t pack4(const char *p, long n)
+{
+    uint8_t b = 0;
+    if (n > 4) n = 4;
+    for (long k = 0; k < n; ++k)
+        b |= (uint8_t)(orc_c2i((unsigned char)p[k]) << (6 - 2 * k));
+    return b;
+}
+
+/* dna_seq.h:86-96 -- byte k of the little-endian word holds bases 4k..4k+3 */
+uint32_t orc_encode(const char *t)
+{
+    return (uint32_t)pack4(t, 4) | (uint32_t)pack4(t + 4, 4) << 8 |
+           (uint32_t)pack4(t + 8, 4) << 16 | (uint32_t)pack4(t + 12, 4) << 24;
+}
+
+uint32_t orc_encode_padded(const char *t, long avail)
+{
+    char w[16];
+    for (int k = 0; k < 16; ++k)
+        w[k] = (k < avail) ? t[k] : '\0';     /* NUL -> code 3 (locator.cpp:26,62-63) */
+    return orc_encode(w);
+}
+
+/* dna_seq.h:101-107 */
+void orc_decode(uint32_t code, char *t)
+{
+    for (int k = 0; k < 4; ++k) {
+        uint8_t b = (uint8_t)(code >> (8 * k));
+        for (int q = 0; q < 4; ++q)
+            t[4 * k + q] = ORC_I2C[(b >> (6 - 2 * q)) & 3];
+    }
+}
+
+/* dna_seq.h:113-127 -- record = u32 length in bases + ceil(len/4) packed bytes */
+size_t orc_text2bin(const char *text, size_t tlen, uint8_t *rec, size_t cap)
+{
+    size_t blen = 4 + (tlen + 3) / 4;
+    if (cap < blen) return 0;
+    uint32_t l32 = (uint32_t)tlen;
+    memcpy(rec, &l32, 4);
+    uint8_t *pb = rec + 4;
+    for (size_t i = 0; i < tlen; i += 4)
+        *pb++ = pack4(text + i, (long)(tlen - i));
+    return blen;
+}
+
+/* dna_seq.h:133-145 -- writes the NUL as well */
+size_t orc_bin2text(const uint8_t *rec, char *text, size_t cap)
+{
+    uint32_t tlen;
+    memcpy(&tlen, rec, 4);
+    if (cap <= tlen) return 0;
+    for (uint32_t i = 0; i < tlen; ++i)
+        text[i] = ORC_I2C[(rec[4 + (i >> 2)] >> (6 - 2 * (i & 3))) & 3];
+    text[tlen] = '\0';
+    return tlen;
+}
+
+/* dna_seq.h:62-76.  For pos%4==0 the reference adds `pos` as a BYTE offset, so it
+ * returns the window of base 4*pos (correct only at pos 0): kept as is. */
+uint32_t orc_seed_at(const uint8_t *rec, int pos)
+{
+    const uint8_t *p = rec + 4;
+    uint32_t w;
+    if ((pos & 3) == 0) {
+        memcpy(&w, p + pos, 4);
+        return w;
+    }
+    p += pos >> 2;
+    unsigned ls = (unsigned)(pos & 3) << 1, rs = 8 - ls;
+    uint8_t s[4];
+    for (int k = 0; k < 4; ++k)
+        s[k] = (uint8_t)((p[k] << ls) | (p[k + 1] >> rs));
+    memcpy(&w, s, 4);
+    return w;
+}
+
+uint32_t orc_seed_at_fixed(const uint8_t *rec, int pos)
+{
+    const uint8_t *p = rec + 4 + (pos >> 2);
+    unsigned ls = (unsigned)(pos & 3) << 1;
+    uint8_t s[4];
+    for (int k = 0; k < 4; ++k)
+        s[k] = ls ? (uint8_t)((p[k] << ls) | (p[k + 1] >> (8 - ls))) : p[k];
+    uint32_t w;
+    memcpy(&w, s, 4);
+    return w;
+}
+
+/* spaced_seed.cpp:167-180 / locator.cpp:51-54: '1' -> T (both bits set), else A; pad with A */
+uint32_t orc_mask_from_pattern(const char *pat)
+{
+    char w[16];
+    size_t n = strlen(pat);
+    if (n > 16) n = 16;
+    for (size_t k = 0; k < 16; ++k)
+        w[k] = (k < n && pat[k] == '1') ? 'T' : 'A';
+    return orc_encode(w);
+}
+
+/* ======================================================================== */
+/* banded DP                                                                */
+/* ======================================================================== */
+
+typedef struct { int cost; int parent; } orc_cell;     /* seq_aligner.h:60-63 */
+enum { OP_MATCH = 1, OP_INSERT = 2, OP_DELETE = 3 };   /* seq_aligner.h:32-36 */
+
+struct orc_aligner {
+    int maxn, maxm;
+    orc_cell *mat;
+    size_t cap;       /* cells allocated */
+};
+
+orc_aligner *orc_aligner_new(int maxn, int maxm)
+{
+    orc_aligner *al = (orc_aligner *)calloc(1, sizeof *al);
+    if (al) { al->maxn = maxn; al->maxm = maxm; }
+    return al;
+}
+
+void orc_aligner_free(orc_aligner *al)
+{
+    if (!al) return;
+    free(al->mat);
+    free(al);
+}
+
+static inline char acc_at(const char *p, int fwd, int k) { return fwd ? p[k] : p[-k]; }
+
+int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
+              const char *b, int b_fwd, int lb, double R,
+              orc_result *res, uint8_t *ops)
+{
+    int len_a, len_b, max_dst;
+    memset(res, 0, sizeof *res);
+    res->rc = -1;
+
+    /* seq_aligner.h:94-102 */
+    if (lb >= la) {
+        len_a = la;
+        max_dst = 1 + (int)(len_a * R);
+        len_b = lb < len_a + max_dst ? lb : len_a + max_dst;
+    } else {
+        len_b = lb;
+        max_dst = 1 + (int)(len_b * R);
+        len_a = la < len_b + max_dst ? la : len_b + max_dst;
+    }
+    res->len_a = len_a; res->len_b = len_b; res->max_dst = max_dst;
+
+    /* seq_aligner.h:104-107 */
+    if (al->maxn > 0 && (len_a >= al->maxn + al->maxm || max_dst >= al->maxm))
+        return -1;
+
+    const size_t W = 2 * (size_t)max_dst + 1;           /* own cells for every band row */
+    const size_t need = ((size_t)len_a + 1) * W;
+    if (need > al->cap) {
+        free(al->mat);
+        al->mat = (orc_cell *)malloc(need * sizeof(orc_cell));
+        if (!al->mat) { al->cap = 0; return -1; }
+        al->cap = need;
+    }
+    orc_cell *mat = al->mat;
+#define CELL(i, j) mat[(size_t)(i) * W + (size_t)((j) - (i) + max_dst)]
+
+    /* init_cell, seq_aligner.h:139-150 */
+    for (int i = 1; i <= max_dst && i <= len_a; ++i) { CELL(i, 0).cost = i; CELL(i, 0).parent = OP_DELETE; }
+    for (int j = 1; j <= max_dst; ++j) { CELL(0, j).cost = j; CELL(0, j).parent = OP_INSERT; }
+    CELL(0, 0).cost = 0; CELL(0, 0).parent = 0;
+
+    /* search, seq_aligner.h:151-190 */
+    int64_t cells = 0;
+    for (int i = 1; i <= len_a; ++i) {
+        const char c = acc_at(a, a_fwd, i - 1);
+        const int beg = i - max_dst > 1 ? i - max_dst : 1;
+        const int end = i + max_dst < len_b ? i + max_dst : len_b;
+        for (int j = beg; j <= end; ++j) {
+            const char d = acc_at(b, b_fwd, j - 1);
+            int t;
+            int cost = CELL(i - 1, j - 1).cost + (c != d);
+            int src = OP_MATCH;
+            if (i - j < max_dst && (t = CELL(i, j - 1).cost + 1) < cost) { cost = t; src = OP_INSERT; }
+            if (j - i < max_dst && (t = CELL(i - 1, j).cost + 1) < cost) { cost = t; src = OP_DELETE; }
+            CELL(i, j).cost = cost;
+            CELL(i, j).parent = src;
+        }
+        cells += end >= beg ? end - beg + 1 : 0;
+        /* early failure, seq_aligner.h:185; the i<=len_b guard is the canonical
+         * reading of an unwritten diagonal cell */
+        if (i > 10 && i <= len_b && (double)CELL(i, i).cost > i * R) {
+            res->fail_row = i;
+            res->cells = cells;
+            return -1;
+        }
+    }
+    res->cells = cells;
+
+    /* goal_cell, seq_aligner.h:191-213 */
+    int matlen_a, matlen_b;
+    if (len_a > len_b) {
+        matlen_a = matlen_b = len_b;
+        int best = CELL(len_b, len_b).cost;
+        for (int i = len_b + 1; i <= len_a; ++i)
+            if (CELL(i, len_b).cost < best) { best = CELL(i, len_b).cost; matlen_a = i; }
+    } else {
+        matlen_a = matlen_b = len_a;
+        int best = CELL(len_a, len_a).cost;
+        for (int j = len_a + 1; j <= len_b; ++j)
+            if (CELL(len_a, j).cost < best) { best = CELL(len_a, j).cost; matlen_b = j; }
+    }
+    res->matlen_a = matlen_a; res->matlen_b = matlen_b;
+    res->cost = CELL(matlen_a, matlen_b).cost;
+
+    /* acceptance, seq_aligner.h:114 */
+    if (matlen_b < len_b * (1 - R)) return -1;
+
+    /* find_path, seq_aligner.h:214-233, walked iteratively from the goal */
+    int n = 0, i = matlen_a, j = matlen_b;
+    for (;;) {
+        int p = CELL(i, j).parent;
+        if (p == OP_MATCH) { --i; --j; }
+        else if (p == OP_INSERT) { --j; }
+        else if (p == OP_DELETE) { --i; }
+        else break;
+        if (ops) ops[n] = (uint8_t)p;
+        ++n;
+    }
+    if (ops)
+        for (int x = 0, y = n - 1; x < y; ++x, --y) { uint8_t t = ops[x]; ops[x] = ops[y]; ops[y] = t; }
+    res->nedit = n;
+#undef CELL
+    res->rc = matlen_b;
+    return matlen_b;
+}
+
+/* ======================================================================== */
+/* seed index: chained hash map, key -> list of positions in insertion order */
+/* (common.h:54: hash_map<unsigned, list<int>>, identity hash)               */
+/* ======================================================================== */
+
+typedef struct orc_pnode { int32_t pos; struct orc_pnode *next; } orc_pnode;
+typedef struct orc_knode {
+    uint32_t key; int32_t n;
+    orc_pnode *head, *tail;
+    struct orc_knode *next;
+} orc_knode;
+
+struct orc_seedmap {
+    size_t nb, nkeys, nentries;
+    orc_knode **b;
+};
+
+orc_seedmap *orc_seedmap_new(size_t nb)
+{
+    orc_seedmap *sm = (orc_seedmap *)calloc(1, sizeof *sm);
+    if (!sm) return NULL;
+    if (nb < 16) nb = 16;
+    sm->nb = nb;
+    sm->b = (orc_knode **)calloc(nb, sizeof *sm->b);
+    if (!sm->b) { free(sm); return NULL; }
+    return sm;
+}
+
+void orc_seedmap_clear(orc_seedmap *sm)
+{
+    for (size_t i = 0; i < sm->nb; ++i) {
+        orc_knode *k = sm->b[i];
+        while (k) {
+            orc_pnode *p = k->head;
+            while (p) { orc_pnode *q = p->next; free(p); p = q; }
+            orc_knode *kn = k->next; free(k); k = kn;
+        }
+        sm->b[i] = NULL;
+    }
+    sm->nkeys = sm->nentries = 0;
+}
+
+void orc_seedmap_free(orc_seedmap *sm)
+{
+    if (!sm) return;
+    orc_seedmap_clear(sm);
+    free(sm->b);
+    free(sm);
+}
+
+size_t orc_seedmap_size(const orc_seedmap *sm) { return sm->nkeys; }
+size_t orc_seedmap_entries(const orc_seedmap *sm) { return sm->nentries; }
+
+static const orc_knode *sm_find(const orc_seedmap *sm, uint32_t key)
+{
+    for (const orc_knode *k = sm->b[key % sm->nb]; k; k = k->next)
+        if (k->key == key) return k;
+    return NULL;
+}
+
+static void sm_push(orc_seedmap *sm, uint32_t key, int32_t pos)
+{
+    orc_knode **slot = &sm->b[key % sm->nb], *k;
+    for (k = *slot; k; k = k->next)
+        if (k->key == key) break;
+    if (!k) {
+        k = (orc_knode *)calloc(1, sizeof *k);
+        k->key = key; k->next = *slot; *slot = k;
+        ++sm->nkeys;
+    }
+    orc_pnode *p = (orc_pnode *)malloc(sizeof *p);
+    p->pos = pos; p->next = NULL;
+    if (k->tail) k->tail->next = p; else k->head = p;
+    k->tail = p;
+    ++k->n; ++sm->nentries;
+}
+
+/* locator.cpp:62-66 */
+size_t orc_index_all(orc_seedmap *sm, const char *text, int len, uint32_t mask)
+{
+    for (int i = 0; i < len; ++i) {
+        uint32_t sd = orc_encode_padded(text + i, (long)len - i);
+        if (sd & mask) sm_push(sm, sd & mask, i);
+    }
+    return sm->nentries;
+}
+
+/* ref_seq.h:291-311; MAX_READ_LEN=20000 (common.h:33), N_SEQ_WORD=16 (dna_seq.h:26) */
+unsigned orc_index_head_tail(orc_seedmap *sm, const char *text, int len, uint32_t mask)
+{
+    const int MAXRD = 20000, NW = 16;
+    int nmax = len - NW;
+    int nhead = nmax < MAXRD ? nmax : MAXRD;
+    orc_seedmap_clear(sm);
+    for (int i = 0; i < nhead; ++i) {
+        uint32_t sd = orc_encode(text + i);
+        if (sd & mask) sm_push(sm, sd & mask, i);
+    }
+    int ntail = len - MAXRD - NW < MAXRD ? len - MAXRD - NW : MAXRD;
+    for (int i = 0; i < ntail; ++i) {
+        uint32_t sd = orc_encode(text + len - NW - i);
+        if (sd & mask) sm_push(sm, sd & mask, len - i - NW);
+    }
+    return (unsigned)(nhead + (ntail < 0 ? 0 : ntail));
+}
+
+int orc_seedmap_find(const orc_seedmap *sm, uint32_t key, int32_t *pos, int cap)
+{
+    const orc_knode *k = sm_find(sm, key);
+    if (!k) return 0;
+    int n = 0;
+    for (const orc_pnode *p = k->head; p; p = p->next, ++n)
+        if (pos && n < cap) pos[n] = p->pos;
+    return n;
+}
+
+static int cmp_knode(const void *x, const void *y)
+{
+    uint32_t a = (*(const orc_knode *const *)x)->key, b = (*(const orc_knode *const *)y)->key;
+    return a < b ? -1 : a > b;
+}
+
+size_t orc_seedmap_dump(const orc_seedmap *sm, uint32_t *keys, int32_t *pos, size_t cap)
+{
+    const orc_knode **ks = (const orc_knode **)malloc((sm->nkeys + 1) * sizeof *ks);
+    size_t nk = 0, n = 0;
+    for (size_t i = 0; i < sm->nb; ++i)
+        for (const orc_knode *k = sm->b[i]; k; k = k->next) ks[nk++] = k;
+    qsort(ks, nk, sizeof *ks, cmp_knode);
+    for (size_t i = 0; i < nk; ++i)
+        for (const orc_pnode *p = ks[i]->head; p; p = p->next, ++n)
+            if (n < cap) { keys[n] = ks[i]->key; pos[n] = p->pos; }
+    free(ks);
+    return n;
+}
+
+/* ======================================================================== */
+/* locator driver                                                           */
+/* ======================================================================== */
+
+typedef struct {
+    const char *contig; int clen; uint32_t mask; double R; int trials, min_len, maxn, maxm;
+    const char *reads; const uint64_t *offs; int nreads;
+    const orc_seedmap *sm;
+    orc_loc_row *rows;
+    volatile int next;
+    pthread_mutex_t mu;
+    orc_loc_stats st;
+} loc_job;
+
+/* one read of the loop at locator.cpp:70-92 */
+static void locate_one(loc_job *J, orc_aligner *al, int r, orc_loc_stats *st)
+{
+    const char *seq = J->reads + J->offs[r];
+    const int len = (int)(J->offs[r + 1] - J->offs[r]);
+    orc_loc_row *row = &J->rows[r];
+    row->found = 0; row->j = -1; row->pos = -1; row->cost = -1; row->seglen = 0;
+    row->matlen_a = row->matlen_b = 0; row->n_pairs = 0;
+    if (len < J->min_len) return;                                   /* locator.cpp:72 */
+    ++st->n_reads_kept;
+    for (int j = 0; j < J->trials && !row->found; ++j) {            /* locator.cpp:74 */
+        uint32_t seed = orc_encode_padded(seq + j, (long)len - j) & J->mask;
+        const orc_knode *k = sm_find(J->sm, seed);                  /* locator.cpp:76 */
+        if (!k) continue;
+        ++st->n_probe_hits;
+        for (const orc_pnode *p = k->head; p; p = p->next) {        /* locator.cpp:79 */
+            orc_result res;
+            ++row->n_pairs; ++st->n_pairs;
+            int rc = orc_align(al, seq + j, 1, len - j,              /* a = read   (locator.cpp:78) */
+                               J->contig + p->pos, 1, J->clen - p->pos, /* b = contig (locator.cpp:80) */
+                               J->R, &res, NULL);
+            st->n_cells += res.cells;
+            if (rc > 0) {                                           /* locator.cpp:82 */
+                row->found = 1; row->j = j; row->pos = p->pos; row->cost = res.cost;
+                row->seglen = len - j; row->matlen_a = res.matlen_a; row->matlen_b = res.matlen_b;
+                ++st->n_located;
+                break;
+            }
+        }
+    }
+}
+
+static void *loc_worker(void *arg)
+{
+    loc_job *J = (loc_job *)arg;
+    orc_aligner *al = orc_aligner_new(J->maxn, J->maxm);
+    orc_loc_stats st; memset(&st, 0, sizeof st);
+    for (;;) {
+        int r = __sync_fetch_and_add(&J->next, 1);
+        if (r >= J->nreads) break;
+        locate_one(J, al, r, &st);
+    }
+    orc_aligner_free(al);
+    pthread_mutex_lock(&J->mu);
+    J->st.n_reads_kept += st.n_reads_kept; J->st.n_probe_hits += st.n_probe_hits;
+    J->st.n_pairs += st.n_pairs; J->st.n_located += st.n_located; J->st.n_cells += st.n_cells;
+    pthread_mutex_unlock(&J->mu);
+    return NULL;
+}
+
+int orc_locator_run(const char *contig, int clen, uint32_t mask, double R,
+                    int trials, int min_len, int maxn, int maxm,
+                    const char *reads, const uint64_t *offs, int nreads,
+                    int nthreads, orc_loc_row *rows, orc_loc_stats *stats)
+{
+    orc_seedmap *sm = orc_seedmap_new((size_t)1 << 23);             /* locator.cpp:28 */
+    if (!sm) return -1;
+    orc_index_all(sm, contig, clen, mask);
+
+    int nseq = 0;                                                   /* locator.cpp:69,72,91 */
+    for (int r = 0; r < nreads; ++r) {
+        int len = (int)(offs[r + 1] - offs[r]);
+        rows[r].read = r;
+        rows[r].nseq = len < min_len ? -1 : nseq++;
+    }
+
+    loc_job J; memset(&J, 0, sizeof J);
+    J.contig = contig; J.clen = clen; J.mask = mask; J.R = R; J.trials = trials;
+    J.min_len = min_len; J.maxn = maxn; J.maxm = maxm;
+    J.reads = reads; J.offs = offs; J.nreads = nreads; J.sm = sm; J.rows = rows;
+    pthread_mutex_init(&J.mu, NULL);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads == 1) {
+        loc_worker(&J);
+    } else {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, loc_worker, &J);
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+        free(th);
+    }
+    pthread_mutex_destroy(&J.mu);
+    if (stats) *stats = J.st;
+    orc_seedmap_free(sm);
+    return 0;
+}
+
+/* ======================================================================== */
+/* spaced_seed locked round                                                 */
+/* ======================================================================== */
+
+typedef struct {
+    const char *ref; int ref_len; uint32_t mask; double R; int max_trial, overlap_min, buggy;
+    const uint8_t *records; const uint64_t *rec_offs; int nreads;
+    const orc_seedmap *sm; orc_ss_row *rows; volatile int next;
+} ss_job;
+
+/* spaced_seed.cpp:262-298 with ref_seq::try_align (ref_seq.h:259-265) in locked mode */
+static int ss_try(ss_job *J, orc_aligner *al, const uint8_t *rec, const char *txt, int seg_len,
+                  long pos, int dir, orc_ss_row *row)
+{
+    uint32_t sd = J->buggy ? orc_seed_at(rec, (int)pos) : orc_seed_at_fixed(rec, (int)pos);
+    const orc_knode *k = sm_find(J->sm, sd & J->mask);              /* spaced_seed.cpp:265 */
+    if (!k) return 0;
+    ++row->n_trials;
+    const int fwd = dir == 1;
+    const int s_off = fwd ? (int)pos : (int)pos + 15;               /* spaced_seed.cpp:274 */
+    const int s_len = fwd ? seg_len - s_off : s_off + 1;            /* spaced_seed.cpp:275 */
+    if (s_len < J->overlap_min) return 0;                           /* spaced_seed.cpp:280 */
+    for (const orc_pnode *p = k->head; p; p = p->next) {
+        const int r_off = fwd ? p->pos : p->pos + 15;               /* spaced_seed.cpp:285 */
+        const int r_len = fwd ? J->ref_len - r_off : r_off + 1;     /* ref_seq.h:284-285 */
+        orc_result res;
+        ++row->n_pairs;
+        int rc = orc_align(al, J->ref + r_off, fwd, r_len,          /* a = reference (ref_seq.h:264) */
+                           txt + s_off, fwd, s_len, J->R, &res, NULL);
+        if (rc < 0) continue;                                       /* ref_seq.h:264 */
+        if (res.matlen_a < J->overlap_min) continue;                /* ref_seq.h:265 */
+        row->found = 1; row->dir = dir; row->ref_pos = p->pos; row->cost = res.cost;
+        row->matlen_a = res.matlen_a; row->matlen_b = res.matlen_b;
+        return 1;
+    }
+    return 0;
+}
+
+static void *ss_worker(void *arg)
+{
+    ss_job *J = (ss_job *)arg;
+    orc_aligner *al = orc_aligner_new(26000, 6000);                 /* t_aligner, seq_aligner.h:260 */
+    al->maxn = 0;                                                   /* canonical: no aliasing, no size guard */
+    char *txt = (char *)malloc(1 << 20);
+    for (;;) {
+        int r = __sync_fetch_and_add(&J->next, 1);
+        if (r >= J->nreads) break;
+        const uint8_t *rec = J->records + J->rec_offs[r];
+        orc_ss_row *row = &J->rows[r];
+        memset(row, 0, sizeof *row);
+        row->read = r; row->j = -1;
+        int slen = (int)orc_bin2text(rec, txt, 1 << 20);            /* spaced_seed.cpp:116 */
+        for (int j = 0; j < J->max_trial; ++j) {                    /* spaced_seed.cpp:424-426 */
+            if (ss_try(J, al, rec, txt, slen, j, 1, row) ||
+                ss_try(J, al, rec, txt, slen, (long)slen - j - 16, -1, row)) {
+                row->j = j;
+                break;
+            }
+        }
+    }
+    free(txt);
+    orc_aligner_free(al);
+    return NULL;
+}
+
+int orc_spaced_round(const char *ref, int ref_len, uint32_t mask, double R,
+                     int max_trial, int overlap_min, int buggy_seed_at,
+                     const uint8_t *records, const uint64_t *rec_offs, int nreads,
+                     int nthreads, orc_ss_row *rows)
+{
+    orc_seedmap *sm = orc_seedmap_new((size_t)1 << 20);             /* spaced_seed.cpp:88 */
+    if (!sm) return -1;
+    orc_index_head_tail(sm, ref, ref_len, mask);                    /* spaced_seed.cpp:415 */
+    ss_job J; memset(&J, 0, sizeof J);
+    J.ref = ref; J.ref_len = ref_len; J.mask = mask; J.R = R; J.max_trial = max_trial;
+    J.overlap_min = overlap_min; J.buggy = buggy_seed_at;
+    J.records = records; J.rec_offs = rec_offs; J.nreads = nreads; J.sm = sm; J.rows = rows;
+    if (nthreads <= 1) {
+        ss_worker(&J);
+    } else {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, ss_worker, &J);
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+        free(th);
+    }
+    orc_seedmap_free(sm);
+    return 0;
+}
+
+/* spaced_seed.cpp:330-342: keep min_excl < len < max_excl (500 / 20000 in the reference) */
+size_t orc_open_binary(const uint8_t *buf, size_t len, uint32_t min_excl, uint32_t max_excl,
+                       uint64_t *offs, size_t cap, size_t *n_total)
+{
+    size_t kept = 0, total = 0;
+    for (size_t off = 0; off + 4 <= len; ) {
+        uint32_t sl;
+        memcpy(&sl, buf + off, 4);
+        if (sl > min_excl && sl < max_excl) {
+            if (kept < cap) offs[kept] = off;
+            ++kept;
+        }
+        ++total;
+        off += 4 + ((size_t)sl + 3) / 4;
+    }
+    if (n_total) *n_total = total;
+    return kept;
+}

@@ -1,0 +1,89 @@
+// dev_common.h -- device-side helpers shared by the gfx950 kernels of libpba.so.
+#ifndef PBA_DEV_COMMON_H
+#define PBA_DEV_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PBA_WAVE 64
+#define PBA_INF (1 << 29)
+
+// A sequence set as the kernels see it: 2-bit packed bases in the reference byte layout
+// (first base in bits 7:6 of a byte, /root/reference/src/dna_seq.h:147-159).
+struct SeqSetDev {
+    const uint8_t *packed;   // all sequences; >= 64 readable bytes after the last one
+    const uint64_t *off;     // byte offset of sequence i's first packed byte
+    const uint32_t *len;     // length in bases
+};
+
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// The 16-base window at base `p` of a packed sequence as dna_seq::encode would return it
+// (dna_seq.h:86-96: little-endian word whose byte k holds bases 4k..4k+3).  Bases at or
+// beyond `len` read as code 3, which is what locator.cpp:62-63 sees past the contig (NUL).
+__device__ __forceinline__ uint32_t window_key(const uint8_t *seq, uint32_t p, uint32_t len) {
+    const uint64_t be = __builtin_bswap64(ld_u64(seq + (p >> 2)));
+    uint32_t w = (uint32_t)((be << (2 * (p & 3))) >> 32);   // base p in bits 31:30
+    const uint32_t valid = len - p;                        // caller guarantees p < len
+    if (valid < 16) w |= 0xFFFFFFFFu >> (2 * valid);
+    return __builtin_bswap32(w);
+}
+
+// element fetchers for the DP: k-th element of an accessor (dna_seq.h:211,221)
+struct PackedFetch {
+    const uint8_t *seq;   // first packed byte of the sequence
+    int org;              // accessor origin (base index)
+    int dir;              // +1 forward, -1 backward
+    __device__ __forceinline__ int operator()(int k) const {
+        const int idx = org + dir * k;
+        return (seq[idx >> 2] >> (6 - 2 * (idx & 3))) & 3;
+    }
+};
+struct ByteFetch {
+    const uint8_t *org;   // accessor origin (pointer to element 0)
+    int dir;
+    __device__ __forceinline__ int operator()(int k) const { return org[dir * k]; }
+};
+
+// what one alignment produces (seq_aligner.h:73-81 plus the early-failure row)
+struct AlnOut {
+    int rc, cost, matlen_a, matlen_b, len_a, len_b, max_dst, fail_row;
+};
+
+// parameter block of seq_aligner::align, seq_aligner.h:94-102.  The products are formed in
+// FP64 exactly as the reference's `len * R` (int promoted to double, truncation toward zero).
+__device__ __forceinline__ void aln_params(int la, int lb, double R, AlnOut &o) {
+    if (lb >= la) {
+        o.len_a = la;
+        o.max_dst = 1 + (int)((double)la * R);
+        o.len_b = min(lb, la + o.max_dst);
+    } else {
+        o.len_b = lb;
+        o.max_dst = 1 + (int)((double)lb * R);
+        o.len_a = min(la, lb + o.max_dst);
+    }
+    o.rc = -1;
+    o.cost = o.matlen_a = o.matlen_b = o.fail_row = 0;
+}
+
+// band cells the reference sweep evaluates in rows 1..n (seq_aligner.h:158-161), closed form
+__device__ __host__ inline long long band_cells(long long len_b, long long m, long long n) {
+    if (n <= 0) return 0;
+    long long t = len_b - m;
+    long long k = t < 0 ? 0 : (t > n ? n : t);
+    long long s_hi = k * (k + 1) / 2 + k * m + (n - k) * len_b;          // sum of min(len_b, i+m)
+    long long k2 = n < m + 1 ? n : m + 1;
+    long long s_lo = k2 + (n * (n + 1) / 2 - k2 * (k2 + 1) / 2) - (n - k2) * m;   // sum of max(1, i-m)
+    return s_hi - s_lo + n;
+}
+
+#endif

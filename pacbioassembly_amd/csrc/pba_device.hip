@@ -1,0 +1,824 @@
+// pba_device.hip -- gfx950 kernels and the device half of the C ABI (include/pba.h).
+//
+// One process per GPU, one pba_ctx per process, one HIP stream per ctx.  Everything here fails
+// loudly (PBA_E_NODEVICE / PBA_E_HIP): there is no CPU path behind these entry points.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "align_rowsweep.h"
+#include "dev_common.h"
+#include "pba.h"
+#include "pba_internal.h"
+#include "seed_index.h"
+
+// ---------------------------------------------------------------------------------------------
+// host-side objects
+// ---------------------------------------------------------------------------------------------
+struct pba_ctx {
+    int device;
+    hipStream_t own_stream, stream;
+    hipDeviceProp_t prop;
+    char err[512];
+};
+
+struct pba_seqs {
+    pba_ctx *ctx;
+    uint32_t n, max_len;
+    uint64_t packed_bytes;   // packed payload resident in HBM (incl. alignment padding)
+    uint8_t *d_packed;
+    uint64_t *d_off;
+    uint32_t *d_len;
+    std::vector<uint64_t> h_off;
+    std::vector<uint32_t> h_len;
+    SeqSetDev dev() const { return SeqSetDev{d_packed, d_off, d_len}; }
+};
+
+struct pba_index {
+    pba_ctx *ctx;
+    uint32_t mask, seq_len, visited, nhead;
+    int32_t tail_top;
+    int mode, logP;
+    uint64_t n_entries;
+    uint64_t *d_ent;
+    uint32_t *d_part_off;
+    IndexDev dev() const { return IndexDev{d_ent, d_part_off, logP, mask, nhead, tail_top}; }
+};
+
+static int ctx_fail(pba_ctx *ctx, int st, const char *what, hipError_t e) {
+    if (ctx)
+        snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, e == hipSuccess ? pba_strerror(st) : hipGetErrorString(e));
+    return st;
+}
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t e__ = (call);                                            \
+        if (e__ != hipSuccess) return ctx_fail(ctx, PBA_E_HIP, #call, e__); \
+    } while (0)
+#define PBA_FAIL(st, what) return ctx_fail(ctx, (st), (what), hipSuccess)
+
+// engine limits
+static const int kMaxSeqLen = 65000;            // u16 DP costs: D(i,j) <= max(i,j) < 65535
+static const int kRowSweepLdsCap = 96 * 1024;   // LDS bytes one wavefront may take for its band row
+static const size_t kSlack = 64;                // readable bytes after the last packed byte
+
+// RAII for temporaries so early returns do not leak device memory
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// kernels: packing
+// ---------------------------------------------------------------------------------------------
+// ASCII -> 2-bit, 16 chars per thread into one packed dword.  Thread t owns packed dword t of the
+// whole set; its sequence is found by bisection over the (16-byte aligned) packed offsets.
+__global__ void __launch_bounds__(256)
+k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_off, const uint32_t *len, uint32_t n,
+            uint64_t total_dwords, uint8_t *packed, int strict, uint32_t *bad) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_dwords) return;
+    const uint64_t byte = t * 4;
+    uint32_t lo = 0, hi = n;            // last s with pk_off[s] <= byte
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pk_off[mid] <= byte) lo = mid; else hi = mid;
+    }
+    const uint32_t s = lo;
+    const uint32_t L = len[s];
+    const uint64_t w = (byte - pk_off[s]) >> 2;          // dword index inside the sequence
+    if (w * 16 >= L) return;                             // alignment padding
+    const uint8_t *src = text + text_off[s] + w * 16;
+    const uint32_t nb = (uint32_t)min((uint64_t)16, (uint64_t)L - w * 16);
+    uint32_t word = 0, notacgt = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t ch = src[k];
+        const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;   // C2I, dna_seq.h:21
+        notacgt |= (code == 3u && ch != 'T');
+        word |= code << (8 * (k >> 2) + 6 - 2 * (k & 3));   // byte k/4, first base in bits 7:6
+    }
+    *reinterpret_cast<uint32_t *>(packed + byte) = word;    // padding bytes of the last dword stay 0
+    if (strict && notacgt) atomicOr(bad, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: alignment of explicit pairs
+// ---------------------------------------------------------------------------------------------
+struct AlignCfg {
+    double R;
+    int maxn, maxm;
+    int row_cap;   // u16 cells of LDS per wavefront (row sweep)
+    int kernel;    // pba_kernel
+};
+
+template <class FA, class FB>
+__device__ __forceinline__ void align_dispatch(const FA &fa, int la, const FB &fb, int lb, const AlignCfg &cfg,
+                                               void *lds, AlnOut &o) {
+    align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o);
+}
+
+__device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
+    if ((threadIdx.x & (PBA_WAVE - 1)) == 0) {
+        const bool ok = o.rc >= 0;
+        out->rc = ok ? o.rc : -1;
+        out->cost = ok ? o.cost : 0;
+        out->matlen_a = ok ? o.matlen_a : 0;
+        out->matlen_b = ok ? o.matlen_b : 0;
+        out->len_a = o.len_a; out->len_b = o.len_b; out->max_dst = o.max_dst;
+    }
+}
+
+__global__ void __launch_bounds__(PBA_WAVE)
+k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n, AlignCfg cfg, pba_result *out) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t q = blockIdx.x;
+    if (q >= n) return;
+    const pba_pair pr = pairs[q];
+    PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
+    PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+    AlnOut o;
+    align_dispatch(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
+    store_result(out + q, o);
+}
+
+__global__ void __launch_bounds__(PBA_WAVE)
+k_align_bytes(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b_dir, int lb, AlignCfg cfg,
+              pba_result *out) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    ByteFetch fa{a, a_dir}, fb{b, b_dir};
+    AlnOut o;
+    align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o);
+    store_result(out, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels: drivers.  One wavefront per read walks the reference's ordered candidate loop and
+// stops at the first success, so the pairs it aligns are exactly the pairs the reference aligns.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long pair_cells(const AlnOut &o) {
+    return band_cells(o.len_b, o.max_dst, o.fail_row ? o.fail_row : o.len_a);
+}
+
+// locator.cpp:70-92
+__global__ void __launch_bounds__(PBA_WAVE)
+k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, uint32_t n_reads, int trials, int min_len,
+         AlignCfg cfg, pba_loc_row *rows, long long *stats /* probe hits, cells */) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int len = (int)Rd.len[r];
+    int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0;
+    long long ncell = 0;
+    if (len >= min_len) {                                                   // locator.cpp:72
+        const uint8_t *rseq = Rd.packed + Rd.off[r];
+        const uint8_t *tsq = T.packed + T.off[tseq];
+        const int clen = (int)T.len[tseq];
+        for (int j = 0; j < trials && j < len && !found; ++j) {             // locator.cpp:74
+            const uint32_t key = window_key(rseq, (uint32_t)j, (uint32_t)len) & ix.mask;   // locator.cpp:75
+            if (key == 0) continue;                                         // never inserted, locator.cpp:64
+            uint32_t beg, cnt;
+            ix_find(ix, key, beg, cnt);                                     // locator.cpp:76
+            if (cnt == 0) continue;
+            ++nhit;
+            for (uint32_t h = 0; h < cnt; ++h) {                            // locator.cpp:79
+                const int pos = ix_pos_of(ix, (uint32_t)ix.ent[beg + h]);
+                PackedFetch fa{rseq, j, 1};                                 // a = read from j   (locator.cpp:78)
+                PackedFetch fb{tsq, pos, 1};                                // b = contig from pos (locator.cpp:80)
+                AlnOut o;
+                align_dispatch(fa, len - j, fb, clen - pos, cfg, lds, o);
+                ++npairs;
+                ncell += pair_cells(o);
+                if (o.rc > 0) {                                             // locator.cpp:82
+                    found = 1; fj = j; fpos = pos; fcost = o.cost; fma = o.matlen_a; fmb = o.matlen_b;
+                    break;
+                }
+            }
+        }
+    }
+    if ((threadIdx.x & (PBA_WAVE - 1)) == 0) {
+        pba_loc_row *row = rows + r;          // read / nseq are filled by the host
+        row->found = found; row->j = fj; row->pos = fpos; row->cost = fcost;
+        row->seglen = found ? len - fj : 0; row->matlen_a = fma; row->matlen_b = fmb; row->n_pairs = npairs;
+        if (nhit) atomicAdd((unsigned long long *)&stats[0], (unsigned long long)nhit);
+        if (ncell) atomicAdd((unsigned long long *)&stats[1], (unsigned long long)ncell);
+    }
+}
+
+// one locked round of spaced_seed.cpp:420-437 (try_align :262-298, ref_seq::try_align ref_seq.h:259-265)
+__device__ __forceinline__ uint32_t seed_at_dev(const uint8_t *payload, int pos, uint32_t len, int buggy) {
+    if (buggy && (pos & 3) == 0) return ld_u32(payload + pos);   // dna_seq.h:64: pos used as a byte offset
+    return window_key(payload, (uint32_t)pos, len);
+}
+
+struct SsState {
+    int found, dir, ref_pos, cost, ma, mb, ntrials, npairs;
+};
+
+__device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, int ref_len, const uint8_t *rseq, int slen,
+                                       int pos, int dir, int overlap_min, int buggy, const AlignCfg &cfg, void *lds,
+                                       SsState &st) {
+    if (pos < 0 || pos + 16 > slen) return false;   // the reference only keeps reads > 500 bases
+    const uint32_t key = seed_at_dev(rseq, pos, (uint32_t)slen, buggy) & ix.mask;   // spaced_seed.cpp:265
+    if (key == 0) return false;
+    uint32_t beg, cnt;
+    ix_find(ix, key, beg, cnt);
+    if (cnt == 0) return false;
+    ++st.ntrials;
+    const bool fwd = dir == 1;
+    const int s_off = fwd ? pos : pos + 15;                        // spaced_seed.cpp:274
+    const int s_len = fwd ? slen - s_off : s_off + 1;              // spaced_seed.cpp:275
+    if (s_len < overlap_min) return false;                         // spaced_seed.cpp:280
+    for (uint32_t h = 0; h < cnt; ++h) {
+        const int hit = ix_pos_of(ix, (uint32_t)ix.ent[beg + h]);
+        const int r_off = fwd ? hit : hit + 15;                    // spaced_seed.cpp:285
+        const int r_len = fwd ? ref_len - r_off : r_off + 1;       // ref_seq.h:284-285
+        PackedFetch fa{ref, r_off, fwd ? 1 : -1};                  // a = reference (ref_seq.h:264)
+        PackedFetch fb{rseq, s_off, fwd ? 1 : -1};
+        AlnOut o;
+        align_dispatch(fa, r_len, fb, s_len, cfg, lds, o);
+        ++st.npairs;
+        if (o.rc < 0) continue;                                    // ref_seq.h:264
+        if (o.matlen_a < overlap_min) continue;                    // ref_seq.h:265
+        st.found = 1; st.dir = dir; st.ref_pos = hit; st.cost = o.cost; st.ma = o.matlen_a; st.mb = o.matlen_b;
+        return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(PBA_WAVE)
+k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, uint32_t n_reads, int max_trial,
+               int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const uint8_t *ref = Rf.packed + Rf.off[rseq_id];
+    const int ref_len = (int)Rf.len[rseq_id];
+    const uint8_t *rseq = Rd.packed + Rd.off[r];
+    const int slen = (int)Rd.len[r];
+    SsState st = {0, 0, 0, 0, 0, 0, 0, 0};
+    int fj = -1;
+    for (int j = 0; j < max_trial; ++j) {                          // spaced_seed.cpp:424-426
+        if (ss_try(ix, ref, ref_len, rseq, slen, j, 1, overlap_min, buggy, cfg, lds, st) ||
+            ss_try(ix, ref, ref_len, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, lds, st)) {
+            fj = j;
+            break;
+        }
+    }
+    if ((threadIdx.x & (PBA_WAVE - 1)) == 0) {
+        pba_ss_row *row = rows + r;
+        row->read = (int32_t)r; row->found = st.found; row->j = fj; row->dir = st.dir; row->ref_pos = st.ref_pos;
+        row->cost = st.cost; row->matlen_a = st.ma; row->matlen_b = st.mb; row->n_trials = st.ntrials;
+        row->n_pairs = st.npairs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: context
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int pba_ctx_create(int device_id, pba_ctx **out) {
+    if (!out) return PBA_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PBA_E_NODEVICE;
+    if (device_id < 0 || device_id >= ndev) return PBA_E_NODEVICE;
+    pba_ctx *ctx = new (std::nothrow) pba_ctx();
+    if (!ctx) return PBA_E_NOMEM;
+    ctx->device = device_id;
+    ctx->err[0] = 0;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
+        delete ctx;
+        return PBA_E_NODEVICE;
+    }
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {   // the code object holds gfx950 ISA only
+        delete ctx;
+        return PBA_E_NODEVICE;
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PBA_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    // kernels that take more than the default 64 KB of dynamic LDS
+    const int big = 160 * 1024;
+    (void)hipFuncSetAttribute((const void *)k_part_sort, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_align_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_align_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_locate, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_spaced_round, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    *out = ctx;
+    return PBA_OK;
+}
+
+void pba_ctx_destroy(pba_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *pba_ctx_error(const pba_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int pba_ctx_set_stream(pba_ctx *ctx, void *hip_stream) {
+    if (!ctx) return PBA_E_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PBA_OK;
+}
+
+int pba_ctx_sync(pba_ctx *ctx) {
+    if (!ctx) return PBA_E_INVALID;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_ctx_device_info(const pba_ctx *ctx, char *name, size_t cap, int *n_cu, int *clock_mhz, uint64_t *hbm) {
+    if (!ctx) return PBA_E_INVALID;
+    if (name && cap) snprintf(name, cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
+    if (hbm) *hbm = (uint64_t)ctx->prop.totalGlobalMem;
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: sequence sets
+// ---------------------------------------------------------------------------------------------
+static int seqs_alloc(pba_ctx *ctx, pba_seqs *s, uint64_t packed_bytes) {
+    s->packed_bytes = packed_bytes;
+    HIPCHK(hipMalloc((void **)&s->d_packed, packed_bytes + kSlack));
+    HIPCHK(hipMemsetAsync(s->d_packed, 0, packed_bytes + kSlack, ctx->stream));
+    HIPCHK(hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (s->n + 1)));
+    HIPCHK(hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (s->n + 1)));
+    HIPCHK(hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * s->n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s->d_len, s->h_len.data(), sizeof(uint32_t) * s->n, hipMemcpyHostToDevice, ctx->stream));
+    return PBA_OK;
+}
+
+void pba_seqs_destroy(pba_seqs *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_packed) (void)hipFree(s->d_packed);
+    if (s->d_off) (void)hipFree(s->d_off);
+    if (s->d_len) (void)hipFree(s->d_len);
+    delete s;
+}
+
+// shared tail of the two text constructors: d_text / d_toff are on the device, h_toff on the host
+static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff, const uint64_t *h_toff, uint32_t n,
+                     int strict, pba_seqs **out) {
+    pba_seqs *s = new (std::nothrow) pba_seqs();
+    if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
+    s->ctx = ctx; s->n = n; s->max_len = 0; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->h_off.resize(n + 1); s->h_len.resize(n + 1);
+    uint64_t pk = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (h_toff[i + 1] < h_toff[i] || h_toff[i + 1] - h_toff[i] > 0x7FFFFFF0ull) {
+            delete s;
+            PBA_FAIL(PBA_E_INVALID, "offsets must be non-decreasing and each sequence < 2^31 bases");
+        }
+        const uint32_t L = (uint32_t)(h_toff[i + 1] - h_toff[i]);
+        s->h_off[i] = pk; s->h_len[i] = L;
+        s->max_len = std::max(s->max_len, L);
+        pk += (((uint64_t)L + 3) / 4 + 15) & ~15ull;     // every sequence starts 16-byte aligned
+    }
+    s->h_off[n] = pk; s->h_len[n] = 0;
+    int st = seqs_alloc(ctx, s, pk);
+    if (st != PBA_OK) { pba_seqs_destroy(s); return st; }
+    DevBuf bad;
+    if (hipMalloc(&bad.p, 4) != hipSuccess) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_NOMEM, "hipMalloc"); }
+    (void)hipMemsetAsync(bad.p, 0, 4, ctx->stream);
+    // the kernel bisects over n+1 offsets: upload the end offset too
+    (void)hipMemcpyAsync(s->d_off + n, &s->h_off[n], sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    const uint64_t total_dwords = pk / 4;
+    if (total_dwords) {
+        const uint64_t blocks = (total_dwords + 255) / 256;
+        if (blocks > 0x7FFFFFFFull) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_TOOLONG, "sequence set too large"); }
+        hipLaunchKernelGGL(k_pack_text, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_text, d_toff, s->d_off,
+                           s->d_len, n, total_dwords, s->d_packed, strict, bad.as<uint32_t>());
+    }
+    uint32_t h_bad = 0;
+    hipError_t e = hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "k_pack_text", e); }
+    if (strict && h_bad) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_ALPHABET, "pba_seqs_from_text"); }
+    *out = s;
+    return PBA_OK;
+}
+
+int pba_seqs_from_text(pba_ctx *ctx, const char *text, const uint64_t *offsets, uint32_t n, int strict_acgt,
+                       pba_seqs **out) {
+    if (!ctx || !offsets || !out || (!text && n && offsets[n] > offsets[0])) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t total = n ? offsets[n] : 0;
+    DevBuf d_text, d_toff;
+    HIPCHK(hipMalloc(&d_text.p, total + kSlack));
+    HIPCHK(hipMalloc(&d_toff.p, sizeof(uint64_t) * (n + 1)));
+    if (total) HIPCHK(hipMemcpyAsync(d_text.p, text, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_toff.p, offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    return seqs_pack(ctx, d_text.as<uint8_t>(), d_toff.as<uint64_t>(), offsets, n, strict_acgt, out);
+}
+
+int pba_seqs_from_device_text(pba_ctx *ctx, const void *d_text, const void *d_offsets, uint32_t n, uint64_t total_bytes,
+                              uint32_t max_len, pba_seqs **out) {
+    (void)total_bytes; (void)max_len;
+    if (!ctx || !d_offsets || !out || (!d_text && n)) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> h_toff(n + 1);
+    HIPCHK(hipMemcpyAsync(h_toff.data(), d_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return seqs_pack(ctx, (const uint8_t *)d_text, (const uint64_t *)d_offsets, h_toff.data(), n, 0, out);
+}
+
+int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, uint32_t min_excl, uint32_t max_excl,
+                          pba_seqs **out) {
+    if (!ctx || !out || (!file && file_len)) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t total = 0;
+    const size_t kept = pba_open_binary(file, file_len, min_excl, max_excl, nullptr, 0, &total);
+    if (kept > 0x7FFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "too many records");
+    std::vector<uint64_t> recs(kept + 1);
+    pba_open_binary(file, file_len, min_excl, max_excl, recs.data(), kept, nullptr);
+    pba_seqs *s = new (std::nothrow) pba_seqs();
+    if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
+    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->h_off.resize(kept + 1); s->h_len.resize(kept + 1);
+    for (size_t i = 0; i < kept; ++i) {
+        uint32_t L;
+        memcpy(&L, file + recs[i], 4);
+        if (recs[i] + 4 + ((uint64_t)L + 3) / 4 > file_len) { delete s; PBA_FAIL(PBA_E_INVALID, "truncated record"); }
+        s->h_off[i] = recs[i] + 4;      // payload follows the u32 length (dna_seq.h:119-121)
+        s->h_len[i] = L;
+        s->max_len = std::max(s->max_len, L);
+    }
+    s->h_off[kept] = file_len; s->h_len[kept] = 0;
+    // the file image goes up as it is (no re-packing); the slack after it is large enough for
+    // seed_at's byte-offset reads to stay inside the allocation and read zeros
+    const uint64_t slack = 65536;
+    s->packed_bytes = file_len;
+    hipError_t e = hipMalloc((void **)&s->d_packed, file_len + slack);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_packed, 0, file_len + slack, ctx->stream);
+    if (e == hipSuccess && file_len) e = hipMemcpyAsync(s->d_packed, file, file_len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (kept + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (kept + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * (kept + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_len, s->h_len.data(), sizeof(uint32_t) * (kept + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "pba_seqs_from_records", e); }
+    *out = s;
+    return PBA_OK;
+}
+
+uint32_t pba_seqs_count(const pba_seqs *s) { return s ? s->n : 0; }
+uint32_t pba_seqs_max_len(const pba_seqs *s) { return s ? s->max_len : 0; }
+uint64_t pba_seqs_packed_bytes(const pba_seqs *s) { return s ? s->packed_bytes : 0; }
+
+int pba_seqs_lengths(const pba_seqs *s, uint32_t *lengths, uint32_t cap) {
+    if (!s || !lengths) return PBA_E_INVALID;
+    for (uint32_t i = 0; i < s->n && i < cap; ++i) lengths[i] = s->h_len[i];
+    return PBA_OK;
+}
+
+int pba_seqs_get_text(pba_ctx *ctx, const pba_seqs *s, uint32_t i, char *text, size_t cap) {
+    if (!ctx || !s || !text || i >= s->n) return PBA_E_INVALID;
+    const uint32_t L = s->h_len[i];
+    if (cap <= L) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint8_t> pk(((size_t)L + 3) / 4 + 1);
+    if (L) HIPCHK(hipMemcpyAsync(pk.data(), s->d_packed + s->h_off[i], ((size_t)L + 3) / 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    static const char base[4] = {'A', 'C', 'G', 'T'};
+    for (uint32_t k = 0; k < L; ++k) text[k] = base[(pk[k >> 2] >> (6 - 2 * (k & 3))) & 3];
+    text[L] = 0;
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: seed index
+// ---------------------------------------------------------------------------------------------
+void pba_index_destroy(pba_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    if (ix->d_ent) (void)hipFree(ix->d_ent);
+    if (ix->d_part_off) (void)hipFree(ix->d_part_off);
+    delete ix;
+}
+
+uint64_t pba_index_entries(const pba_index *ix) { return ix ? ix->n_entries : 0; }
+uint32_t pba_index_visited(const pba_index *ix) { return ix ? ix->visited : 0; }
+
+// sort one oversize partition in global memory
+static int sort_partition_global(pba_ctx *ctx, uint64_t *d_part, uint32_t n) {
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    DevBuf tmp;
+    HIPCHK(hipMalloc(&tmp.p, sizeof(uint64_t) * N));
+    HIPCHK(hipMemcpyAsync(tmp.p, d_part, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (N > n)
+        hipLaunchKernelGGL(k_fill_u64, dim3((N - n + 255) / 256), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(), n, N,
+                           ~0ull);
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1)
+            hipLaunchKernelGGL(k_bitonic_step, dim3((N / 2 + 255) / 256), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(),
+                               N, k, j);
+    HIPCHK(hipMemcpyAsync(d_part, tmp.p, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode, pba_index **out) {
+    if (!ctx || !target || !out || seq >= target->n) return PBA_E_INVALID;
+    if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t len = target->h_len[seq];
+    if (len > 0x7FFFFFF0u) PBA_FAIL(PBA_E_TOOLONG, "target sequence");
+
+    // the reference's visiting order, as at most two position segments
+    ScanSeg segs[2];
+    int nseg = 0;
+    uint32_t visited = 0, nhead = 0xFFFFFFFFu;
+    int32_t tail_top = 0;
+    if (mode == PBA_INDEX_ALL) {                       // locator.cpp:62: for i in [0, len)
+        if (len) segs[nseg++] = ScanSeg{0, len, 0, 0};
+        visited = len;
+    } else {                                           // ref_seq.h:291-311, MAX_READ_LEN = 20000, N_SEQ_WORD = 16
+        const long long L = len, nmax = L - 16;
+        const long long nh = std::min(nmax, 20000ll);
+        const long long nt = std::min(L - 20000 - 16, 20000ll);
+        nhead = nh > 0 ? (uint32_t)nh : 0;
+        tail_top = (int32_t)(L - 16);
+        if (nh > 0) segs[nseg++] = ScanSeg{0, (uint32_t)nh, 0, 0};
+        if (nt > 0) segs[nseg++] = ScanSeg{(uint32_t)(L - 16 - nt + 1), (uint32_t)(L - 16 + 1), nhead, 1};
+        visited = (uint32_t)((nh > 0 ? nh : 0) + (nt > 0 ? nt : 0));   // the int the reference returns, for sane inputs
+        if (nh < 0) visited = (uint32_t)(nh + (nt < 0 ? 0 : nt));      // (ref_seq.h:310 adds a negative nhead as is)
+    }
+
+    pba_index *ix = new (std::nothrow) pba_index();
+    if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
+    ix->ctx = ctx; ix->mask = mask; ix->seq_len = len; ix->visited = visited; ix->nhead = nhead;
+    ix->tail_top = tail_top; ix->mode = mode; ix->n_entries = 0; ix->d_ent = nullptr; ix->d_part_off = nullptr;
+    uint64_t npos = 0;
+    for (int s = 0; s < nseg; ++s) npos += segs[s].hi - segs[s].lo;
+    int logP = 0;
+    while (logP < PBA_IX_MAX_LOGP && (npos >> logP) > 1024) ++logP;
+    ix->logP = logP;
+    const uint32_t P = 1u << logP;
+
+    const uint8_t *d_seq = target->d_packed + target->h_off[seq];
+    DevBuf cnt;
+    std::vector<uint32_t> h_cnt(P + 1, 0), h_off(P + 1, 0);
+    hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_part_off, sizeof(uint32_t) * (P + 1));
+    if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
+    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
+    auto seg_grid = [](const ScanSeg &sg) {
+        const uint64_t chunks = ((uint64_t)sg.hi + 15) / 16 - sg.lo / 16;
+        return (uint32_t)((chunks + PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS - 1) / (PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS));
+    };
+    for (int s = 0; s < nseg; ++s)
+        hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+                           mask, segs[s], logP, cnt.as<uint32_t>());
+    e = hipMemcpyAsync(h_cnt.data(), cnt.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "k_seed_count", e); }
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < P; ++p) { h_off[p] = (uint32_t)total; total += h_cnt[p]; }
+    h_off[P] = (uint32_t)total;
+    ix->n_entries = total;
+    e = hipMalloc((void **)&ix->d_ent, sizeof(uint64_t) * (total + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_part_off, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt.p, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream);   // cursors
+    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index entries", e); }
+    if (total) {
+        for (int s = 0; s < nseg; ++s)
+            hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq,
+                               len, mask, segs[s], logP, cnt.as<uint32_t>(), ix->d_ent);
+        hipLaunchKernelGGL(k_part_sort, dim3(P), dim3(256), sizeof(uint64_t) * PBA_IX_LDS_SORT_CAP, ctx->stream,
+                           ix->d_ent, ix->d_part_off);
+        e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "k_seed_scatter/k_part_sort", e); }
+        for (uint32_t p = 0; p < P; ++p)
+            if (h_cnt[p] > PBA_IX_LDS_SORT_CAP) {
+                int st = sort_partition_global(ctx, ix->d_ent + h_off[p], h_cnt[p]);
+                if (st != PBA_OK) { pba_index_destroy(ix); return st; }
+            }
+    }
+    *out = ix;
+    return PBA_OK;
+}
+
+int pba_index_dump(pba_ctx *ctx, const pba_index *ix, uint32_t *keys, int32_t *pos, uint64_t cap, uint64_t *n) {
+    if (!ctx || !ix || !n) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    *n = ix->n_entries;
+    if (!keys || !pos) return PBA_OK;
+    std::vector<uint64_t> ent(ix->n_entries + 1);
+    if (ix->n_entries)
+        HIPCHK(hipMemcpyAsync(ent.data(), ix->d_ent, sizeof(uint64_t) * ix->n_entries, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ent.resize(ix->n_entries);
+    std::sort(ent.begin(), ent.end());          // partitions are sorted; this only merges them by key
+    for (uint64_t i = 0; i < ent.size() && i < cap; ++i) {
+        const uint32_t ord = (uint32_t)ent[i];
+        keys[i] = (uint32_t)(ent[i] >> 32);
+        pos[i] = ord < ix->nhead ? (int32_t)ord : ix->tail_top - (int32_t)(ord - ix->nhead);
+    }
+    return PBA_OK;
+}
+
+int pba_index_find(pba_ctx *ctx, const pba_index *ix, const uint32_t *keys, uint32_t n_keys, uint64_t *hit_off,
+                   int32_t *hit_pos, uint64_t hit_cap) {
+    if (!ctx || !ix || !hit_off || (!keys && n_keys)) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    hit_off[0] = 0;
+    if (!n_keys) return PBA_OK;
+    DevBuf d_keys, d_beg, d_cnt, d_off, d_pos;
+    HIPCHK(hipMalloc(&d_keys.p, 4ull * n_keys));
+    HIPCHK(hipMalloc(&d_beg.p, 4ull * n_keys));
+    HIPCHK(hipMalloc(&d_cnt.p, 4ull * n_keys));
+    HIPCHK(hipMemcpyAsync(d_keys.p, keys, 4ull * n_keys, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_find_count, dim3((n_keys + 255) / 256), dim3(256), 0, ctx->stream, ix->dev(),
+                       d_keys.as<uint32_t>(), n_keys, d_beg.as<uint32_t>(), d_cnt.as<uint32_t>());
+    std::vector<uint32_t> cnt(n_keys);
+    HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt.p, 4ull * n_keys, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = 0; q < n_keys; ++q) hit_off[q + 1] = hit_off[q] + cnt[q];
+    const uint64_t total = hit_off[n_keys];
+    if (!hit_pos || !total) return PBA_OK;
+    const uint64_t ncopy = std::min(total, hit_cap);
+    HIPCHK(hipMalloc(&d_off.p, 8ull * (n_keys + 1)));
+    HIPCHK(hipMalloc(&d_pos.p, 4ull * (ncopy + 1)));
+    HIPCHK(hipMemcpyAsync(d_off.p, hit_off, 8ull * (n_keys + 1), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_find_fill, dim3((n_keys + 255) / 256), dim3(256), 0, ctx->stream, ix->dev(), d_beg.as<uint32_t>(),
+                       d_off.as<uint64_t>(), n_keys, d_pos.as<int32_t>(), ncopy);
+    HIPCHK(hipMemcpyAsync(hit_pos, d_pos.p, 4ull * ncopy, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: alignment
+// ---------------------------------------------------------------------------------------------
+static int max_dst_of(int la, int lb, double R) {      // seq_aligner.h:94-102
+    return 1 + (int)((lb >= la ? la : lb) * R);
+}
+
+static int make_cfg(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int max_dst_max, AlignCfg *cfg, size_t *lds) {
+    if (!(R > 0.0) || !(R < 1.0)) PBA_FAIL(PBA_E_INVALID, "R must be in (0,1)");
+    if (kernel != PBA_KERNEL_AUTO && kernel != PBA_KERNEL_ROWSWEEP && kernel != PBA_KERNEL_BITVEC)
+        PBA_FAIL(PBA_E_INVALID, "unknown kernel");
+    const long long W = 2ll * max_dst_max + 1;
+    const long long bytes = ((W * 2 + 15) / 16) * 16;
+    if (bytes > kRowSweepLdsCap) PBA_FAIL(PBA_E_TOOLONG, "band row does not fit the per-wavefront LDS budget");
+    cfg->R = R; cfg->maxn = maxn; cfg->maxm = maxm; cfg->kernel = kernel;
+    cfg->row_cap = (int)(bytes / 2);
+    *lds = (size_t)bytes;
+    return PBA_OK;
+}
+
+static bool pair_ok(const pba_seqs *S, uint32_t seq, int pos, int len, bool backward) {
+    if (seq >= S->n || len < 0 || len > kMaxSeqLen || pos < 0) return false;
+    const long long L = S->h_len[seq];
+    if (len == 0) return pos <= L;
+    return backward ? (pos < L && pos - (len - 1) >= 0) : ((long long)pos + len <= L);
+}
+
+int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
+                    int maxn, int maxm, int kernel, pba_result *out) {
+    if (!ctx || !A || !B || (!pairs && n) || (!out && n)) return PBA_E_INVALID;
+    if (n == 0) return PBA_OK;
+    if (n > 0x7FFFFFFFull) PBA_FAIL(PBA_E_INVALID, "too many pairs in one batch");
+    HIPCHK(hipSetDevice(ctx->device));
+    int mdmax = 1;
+    for (size_t q = 0; q < n; ++q) {
+        const pba_pair &p = pairs[q];
+        if (!pair_ok(A, p.a_seq, p.a_pos, p.a_len, p.flags & PBA_A_BACKWARD) ||
+            !pair_ok(B, p.b_seq, p.b_pos, p.b_len, p.flags & PBA_B_BACKWARD))
+            PBA_FAIL(PBA_E_INVALID, "pair outside its sequence (or longer than the engine limit)");
+        if (R > 0.0 && R < 1.0) mdmax = std::max(mdmax, max_dst_of(p.a_len, p.b_len, R));
+    }
+    AlignCfg cfg;
+    size_t lds;
+    int st = make_cfg(ctx, R, maxn, maxm, kernel, mdmax, &cfg, &lds);
+    if (st != PBA_OK) return st;
+    DevBuf d_pairs, d_out;
+    HIPCHK(hipMalloc(&d_pairs.p, sizeof(pba_pair) * n));
+    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
+    HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_align_pairs, dim3((uint32_t)n), dim3(PBA_WAVE), lds, ctx->stream, A->dev(), B->dev(),
+                       d_pairs.as<pba_pair>(), (uint32_t)n, cfg, d_out.as<pba_result>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b, int b_fwd, int lb, double R,
+                   int maxn, int maxm, pba_result *out) {
+    if (!ctx || !out || la < 0 || lb < 0 || (!a && la) || (!b && lb)) return PBA_E_INVALID;
+    if (la > kMaxSeqLen || lb > kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "pba_align_text");
+    HIPCHK(hipSetDevice(ctx->device));
+    AlignCfg cfg;
+    size_t lds;
+    int st = make_cfg(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, max_dst_of(la, lb, R), &cfg, &lds);
+    if (st != PBA_OK) return st;
+    // element k of a backward accessor is p[-k]: ship [p-(len-1), p] and point at its last byte
+    const size_t oa = 0, ob = ((size_t)la + 31) & ~(size_t)15;
+    DevBuf buf, d_out;
+    HIPCHK(hipMalloc(&buf.p, ob + lb + 32));
+    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result)));
+    if (la) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + oa, a_fwd ? a : a - (la - 1), la, hipMemcpyHostToDevice, ctx->stream));
+    if (lb) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + ob, b_fwd ? b : b - (lb - 1), lb, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *da = buf.as<uint8_t>() + oa + (a_fwd || !la ? 0 : la - 1);
+    const uint8_t *db = buf.as<uint8_t>() + ob + (b_fwd || !lb ? 0 : lb - 1);
+    hipLaunchKernelGGL(k_align_bytes, dim3(1), dim3(PBA_WAVE), lds, ctx->stream, da, a_fwd ? 1 : -1, la, db,
+                       b_fwd ? 1 : -1, lb, cfg, d_out.as<pba_result>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: drivers
+// ---------------------------------------------------------------------------------------------
+int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32_t target_seq, const pba_seqs *reads,
+               double R, int trials, int min_len, int maxn, int maxm, int kernel, pba_loc_row *rows,
+               pba_loc_stats *stats) {
+    if (!ctx || !ix || !target || !reads || !rows || target_seq >= target->n || trials < 0) return PBA_E_INVALID;
+    if (ix->mode != PBA_INDEX_ALL || ix->seq_len != target->h_len[target_seq])
+        PBA_FAIL(PBA_E_INVALID, "pba_locate needs a PBA_INDEX_ALL index of the target sequence");
+    if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = reads->n;
+    AlignCfg cfg;
+    size_t lds;
+    int st = make_cfg(ctx, R, maxn, maxm, kernel, 1 + (int)(reads->max_len * R), &cfg, &lds);
+    if (st != PBA_OK) return st;
+    DevBuf d_rows, d_stats;
+    HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_loc_row) * (n + 1)));
+    HIPCHK(hipMalloc(&d_stats.p, 16));
+    HIPCHK(hipMemsetAsync(d_stats.p, 0, 16, ctx->stream));
+    if (n)
+        hipLaunchKernelGGL(k_locate, dim3(n), dim3(PBA_WAVE), lds, ctx->stream, ix->dev(), target->dev(), target_seq,
+                           reads->dev(), n, trials, min_len, cfg, d_rows.as<pba_loc_row>(), d_stats.as<long long>());
+    HIPCHK(hipGetLastError());
+    long long h_stats[2] = {0, 0};
+    if (n) HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_loc_row) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    pba_loc_stats s = {0, 0, 0, 0, 0};
+    int nseq = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+        rows[r].read = (int32_t)r;
+        rows[r].nseq = (int)reads->h_len[r] < min_len ? -1 : nseq++;      // locator.cpp:72,91
+        if (rows[r].nseq >= 0) ++s.n_reads_kept;
+        s.n_pairs += rows[r].n_pairs;
+        s.n_located += rows[r].found;
+    }
+    s.n_probe_hits = h_stats[0];
+    s.n_cells = h_stats[1];
+    if (stats) *stats = s;
+    return PBA_OK;
+}
+
+int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads,
+                     double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel, pba_ss_row *rows) {
+    if (!ctx || !ix || !ref || !reads || !rows || ref_seq >= ref->n || max_trial < 0) return PBA_E_INVALID;
+    if (ix->mode != PBA_INDEX_HEAD_TAIL || ix->seq_len != ref->h_len[ref_seq])
+        PBA_FAIL(PBA_E_INVALID, "pba_spaced_round needs a PBA_INDEX_HEAD_TAIL index of the reference sequence");
+    if (reads->max_len > (uint32_t)kMaxSeqLen || ref->h_len[ref_seq] > 0x7FFFFFF0u)
+        PBA_FAIL(PBA_E_TOOLONG, "sequence longer than the engine limit");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t n = reads->n;
+    AlignCfg cfg;
+    size_t lds;
+    // a = reference window, b = read window: the shorter side bounds max_dst (seq_aligner.h:94-102)
+    int st = make_cfg(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &cfg, &lds);
+    if (st != PBA_OK) return st;
+    DevBuf d_rows;
+    HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_ss_row) * (n + 1)));
+    if (n)
+        hipLaunchKernelGGL(k_spaced_round, dim3(n), dim3(PBA_WAVE), lds, ctx->stream, ix->dev(), ref->dev(), ref_seq,
+                           reads->dev(), n, max_trial, overlap_min, buggy_seed_at, cfg, d_rows.as<pba_ss_row>());
+    HIPCHK(hipGetLastError());
+    if (n) HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// seed_index.h -- device side of the seed-hit index.
+//
+// Replaces hash_table = hash_map<unsigned, list<int>> (/root/reference/src/common.h:54) as built
+// by locator.cpp:62-66 and ref_seq::get_seedmap (ref_seq.h:291-311) and probed by
+// locator.cpp:76 / spaced_seed.cpp:265.
+//
+// Shape: one entry per indexed position, entry = (key << 32) | ord, where key = window & mask
+// (entries with key == 0 are dropped, ref_seq.h:300 / locator.cpp:64) and ord is the position's
+// ordinal in the reference's insertion sequence.  Entries are split into 2^logP hash partitions
+// (multiplicative hash of the key); a partition is sorted by the 64-bit entry, i.e. by key and,
+// inside a key, by insertion order -- exactly the order a list<int> hands back.  A probe hashes
+// to its partition and binary-searches the key's run.
+//
+// Build = coalesced scan of the 2-bit packed bases (0.25 B/base read), per-workgroup LDS
+// histogram of the hash partitions, one global reservation per (workgroup, partition), scatter,
+// then one workgroup per partition sorts its entries in LDS.
+#ifndef PBA_SEED_INDEX_H
+#define PBA_SEED_INDEX_H
+
+#include "dev_common.h"
+
+#define PBA_IX_MAX_LOGP 12                 // <= 4096 partitions: two u32 LDS tables = 32 KB
+#define PBA_IX_LDS_SORT_CAP 16384          // entries one workgroup sorts in LDS (128 KB)
+#define PBA_IX_TILE_THREADS 256
+#define PBA_IX_TILE_ITERS 4
+#define PBA_IX_TILE_POS (PBA_IX_TILE_THREADS * 16 * PBA_IX_TILE_ITERS)   // positions per workgroup
+
+struct IndexDev {
+    const uint64_t *ent;        // entries, partition by partition, each partition sorted
+    const uint32_t *part_off;   // 2^logP + 1 offsets into ent
+    int logP;
+    uint32_t mask;              // spaced-seed mask the index was built under
+    // ord -> position (ref_seq.h:297-308): ord < nhead -> ord, else tail_top - (ord - nhead)
+    uint32_t nhead;
+    int32_t tail_top;
+};
+
+__device__ __forceinline__ uint32_t ix_part(uint32_t key, int logP) {
+    return logP ? (key * 0x9E3779B1u) >> (32 - logP) : 0u;
+}
+
+__device__ __forceinline__ int32_t ix_pos_of(const IndexDev &ix, uint32_t ord) {
+    return ord < ix.nhead ? (int32_t)ord : ix.tail_top - (int32_t)(ord - ix.nhead);
+}
+
+__device__ __forceinline__ uint32_t ix_lower_bound(const uint64_t *ent, uint32_t lo, uint32_t hi, uint64_t x) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (ent[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// hash_table::find: run [beg, beg+cnt) of `key` in reference list order
+__device__ __forceinline__ void ix_find(const IndexDev &ix, uint32_t key, uint32_t &beg, uint32_t &cnt) {
+    const uint32_t p = ix_part(key, ix.logP);
+    const uint32_t lo = ix.part_off[p], hi = ix.part_off[p + 1];
+    beg = ix_lower_bound(ix.ent, lo, hi, (uint64_t)key << 32);
+    const uint32_t end = key == 0xFFFFFFFFu ? hi : ix_lower_bound(ix.ent, beg, hi, (uint64_t)(key + 1) << 32);
+    cnt = end - beg;
+}
+
+// One scan segment: positions [lo, hi) of a sequence, visited ascending (ord = ord0 + pos - lo)
+// or descending (ord = ord0 + hi - 1 - pos).
+struct ScanSeg {
+    uint32_t lo, hi, ord0;
+    int descending;
+};
+
+// keys of the 16 positions [16*chunk, 16*chunk+16) from one 8-byte load of packed bases
+__device__ __forceinline__ uint64_t chunk_bits(const uint8_t *seq, uint32_t chunk) {
+    return __builtin_bswap64(ld_u64(seq + 4 * (size_t)chunk));
+}
+__device__ __forceinline__ uint32_t chunk_key(uint64_t be, uint32_t k, uint32_t pos, uint32_t len, uint32_t mask) {
+    uint32_t w = (uint32_t)((be << (2 * k)) >> 32);
+    const uint32_t valid = len - pos;
+    if (valid < 16) w |= 0xFFFFFFFFu >> (2 * valid);
+    return __builtin_bswap32(w) & mask;
+}
+
+// pass 1: partition sizes
+__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int logP, uint32_t *part_cnt) {
+    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
+    const uint32_t P = 1u << logP;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    const uint32_t chunk0 = sg.lo >> 4;
+    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+        if ((uint64_t)chunk * 16 >= sg.hi) break;
+        const uint64_t be = chunk_bits(seq, chunk);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = chunk * 16 + k;
+            if (pos < sg.lo || pos >= sg.hi) continue;
+            const uint32_t key = chunk_key(be, k, pos, len, mask);
+            if (key) atomicAdd(&hist[ix_part(key, logP)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
+        if (hist[p]) atomicAdd(&part_cnt[p], hist[p]);
+}
+
+// pass 2: scatter entries into their partitions (order inside a partition is fixed by the sort)
+__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int logP, uint32_t *part_cursor,
+               uint64_t *ent) {
+    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
+    __shared__ uint32_t base[1 << PBA_IX_MAX_LOGP];
+    const uint32_t P = 1u << logP;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    const uint32_t chunk0 = sg.lo >> 4;
+    uint64_t be[PBA_IX_TILE_ITERS];
+    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+        be[it] = 0;
+        if ((uint64_t)chunk * 16 >= sg.hi) continue;
+        be[it] = chunk_bits(seq, chunk);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = chunk * 16 + k;
+            if (pos < sg.lo || pos >= sg.hi) continue;
+            const uint32_t key = chunk_key(be[it], k, pos, len, mask);
+            if (key) atomicAdd(&hist[ix_part(key, logP)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+        const uint32_t n = hist[p];
+        base[p] = n ? atomicAdd(&part_cursor[p], n) : 0u;
+        hist[p] = 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+        if ((uint64_t)chunk * 16 >= sg.hi) continue;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = chunk * 16 + k;
+            if (pos < sg.lo || pos >= sg.hi) continue;
+            const uint32_t key = chunk_key(be[it], k, pos, len, mask);
+            if (!key) continue;
+            const uint32_t p = ix_part(key, logP);
+            const uint32_t slot = base[p] + atomicAdd(&hist[p], 1u);
+            const uint32_t ord = sg.ord0 + (sg.descending ? sg.hi - 1 - pos : pos - sg.lo);
+            ent[slot] = (uint64_t)key << 32 | ord;
+        }
+    }
+}
+
+// pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
+__global__ void __launch_bounds__(256) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
+    extern __shared__ __align__(16) uint64_t s_ent[];
+    const uint32_t lo = part_off[blockIdx.x], n = part_off[blockIdx.x + 1] - lo;
+    if (n < 2 || n > PBA_IX_LDS_SORT_CAP) return;     // oversize partitions take the global path
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s_ent[i] = i < n ? ent[lo + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // low element of the pair
+                const uint32_t l = i | j;
+                const uint64_t x = s_ent[i], y = s_ent[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { s_ent[i] = y; s_ent[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) ent[lo + i] = s_ent[i];
+}
+
+// global-memory bitonic step for partitions too large for LDS (low-complexity targets)
+__global__ void k_bitonic_step(uint64_t *buf, uint32_t N, uint32_t k, uint32_t j) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (N >> 1)) return;
+    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    const uint32_t l = i | j;
+    const uint64_t x = buf[i], y = buf[l];
+    const bool up = (i & k) == 0;
+    if ((x > y) == up) { buf[i] = y; buf[l] = x; }
+}
+__global__ void k_fill_u64(uint64_t *buf, uint32_t from, uint32_t to, uint64_t v) {
+    const uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < to) buf[i] = v;
+}
+
+// batch find, two launches: counts, then positions in list order
+__global__ void k_find_count(IndexDev ix, const uint32_t *keys, uint32_t n, uint32_t *beg, uint32_t *cnt) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    uint32_t b = 0, c = 0;
+    if (keys[q]) ix_find(ix, keys[q], b, c);
+    beg[q] = b; cnt[q] = c;
+}
+__global__ void k_find_fill(IndexDev ix, const uint32_t *beg, const uint64_t *hit_off, uint32_t n, int32_t *hit_pos,
+                            uint64_t cap) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const uint64_t o = hit_off[q], c = hit_off[q + 1] - o;
+    for (uint64_t h = 0; h < c && o + h < cap; ++h)
+        hit_pos[o + h] = ix_pos_of(ix, (uint32_t)ix.ent[beg[q] + h]);
+}
+
+#endif

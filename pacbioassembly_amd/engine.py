@@ -1,0 +1,296 @@
+"""Thin Python host layer over the C ABI (include/pba.h) -- used by tests/ and bench.py.
+
+The reference is C++; its drop-in host API is the compat headers in include/compat/.  This module
+only wraps the same C entry points for pytest and the benchmark: numpy arrays in, numpy arrays
+out, every non-zero status raised as PbaError.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (PBA_INDEX_ALL, PBA_INDEX_HEAD_TAIL, PBA_KERNEL_AUTO, PBA_KERNEL_BITVEC, PBA_KERNEL_ROWSWEEP,
+                   PbaLocRow, PbaLocStats, PbaPair, PbaResult, PbaSsRow)
+
+PAIR_DTYPE = np.dtype([("a_seq", "<u4"), ("a_pos", "<i4"), ("a_len", "<i4"), ("b_seq", "<u4"), ("b_pos", "<i4"),
+                       ("b_len", "<i4"), ("flags", "<u4")])
+RESULT_DTYPE = np.dtype([(n, "<i4") for n in ("rc", "cost", "matlen_a", "matlen_b", "len_a", "len_b", "max_dst")])
+LOC_ROW_DTYPE = np.dtype([(n, "<i4") for n in
+                          ("read", "nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs")])
+SS_ROW_DTYPE = np.dtype([(n, "<i4") for n in
+                         ("read", "found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b", "n_trials",
+                          "n_pairs")])
+assert PAIR_DTYPE.itemsize == C.sizeof(PbaPair) and RESULT_DTYPE.itemsize == C.sizeof(PbaResult)
+assert LOC_ROW_DTYPE.itemsize == C.sizeof(PbaLocRow) and SS_ROW_DTYPE.itemsize == C.sizeof(PbaSsRow)
+
+
+class PbaError(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = status
+        msg = _lib.load().pba_strerror(status).decode()
+        super().__init__(f"pba status {status} ({msg})" + (f": {detail}" if detail else ""))
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+# ----------------------------------------------------------------------------- host codec
+def encode(text16: bytes) -> int:
+    assert len(text16) >= 16
+    return _lib.load().pba_encode16(text16)
+
+
+def decode(code: int) -> bytes:
+    buf = C.create_string_buffer(17)
+    _lib.load().pba_decode16(code, buf)
+    return buf.raw[:16]
+
+
+def text2bin(text: bytes) -> bytes:
+    cap = 4 + (len(text) + 3) // 4
+    out = np.zeros(cap, np.uint8)
+    n = _lib.load().pba_text2bin(text, len(text), _ptr(out), cap)
+    assert n == cap
+    return out.tobytes()
+
+
+def bin2text(record: bytes) -> bytes:
+    rec = np.frombuffer(record, np.uint8)
+    ln = int(np.frombuffer(record[:4], "<u4")[0])
+    buf = C.create_string_buffer(ln + 1)
+    n = _lib.load().pba_bin2text(_ptr(rec), buf, ln + 1)
+    return buf.raw[:n]
+
+
+def seed_at(record: bytes, pos: int, fixed: bool = False) -> int:
+    rec = np.frombuffer(record + b"\0" * 64, np.uint8)   # seed_at reads past short records (B1)
+    lib = _lib.load()
+    return (lib.pba_seed_at_fixed if fixed else lib.pba_seed_at)(_ptr(rec), pos)
+
+
+def mask_from_pattern(pattern: str) -> int:
+    return _lib.load().pba_mask_from_pattern(pattern.encode())
+
+
+def open_binary(file: bytes, min_excl: int = 500, max_excl: int = 20000):
+    buf = np.frombuffer(file, np.uint8)
+    total = C.c_size_t(0)
+    lib = _lib.load()
+    kept = lib.pba_open_binary(_ptr(buf), len(file), min_excl, max_excl, None, 0, C.byref(total))
+    offs = np.zeros(max(kept, 1), np.uint64)
+    lib.pba_open_binary(_ptr(buf), len(file), min_excl, max_excl, _ptr(offs), kept, None)
+    return offs[:kept], int(total.value)
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def synth_genome(seed: int, n: int) -> np.ndarray:
+    out = np.empty(n, np.uint8)
+    _lib.load().pba_synth_genome(seed, _ptr(out), n)
+    return out
+
+
+def synth_reads(seed: int, genome: np.ndarray, n_reads: int, read_len: int, p_ins: float = 0.05,
+                p_del: float = 0.05, p_sub: float = 0.05, nthreads: int = 8):
+    """Returns (text[n_reads*read_len] uint8, offsets[n_reads+1] uint64, starts[n_reads] uint32)."""
+    genome = np.ascontiguousarray(genome, np.uint8)
+    out = np.empty(n_reads * read_len, np.uint8)
+    starts = np.empty(max(n_reads, 1), np.uint32)
+    st = _lib.load().pba_synth_reads(seed, _ptr(genome), genome.size, n_reads, read_len, p_ins, p_del, p_sub,
+                                     _ptr(out), _ptr(starts), nthreads)
+    if st != 0:
+        raise PbaError(st, "pba_synth_reads")
+    offs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
+    return out, offs, starts[:n_reads]
+
+
+def concat(seqs: Sequence[bytes]):
+    """Concatenate byte strings into (text uint8[], offsets uint64[n+1])."""
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    if seqs:
+        offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    text = np.frombuffer(b"".join(seqs), np.uint8).copy() if seqs else np.zeros(0, np.uint8)
+    return text, offs
+
+
+# ----------------------------------------------------------------------------- device objects
+class Context:
+    """One GPU, one stream (pba_ctx).  Raises PbaError(PBA_E_NODEVICE) without a gfx950 device."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        st = self.lib.pba_ctx_create(device, C.byref(h))
+        if st != 0:
+            raise PbaError(st, "pba_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pba_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def check(self, st: int, what: str = ""):
+        if st != 0:
+            raise PbaError(st, f"{what}: {self.lib.pba_ctx_error(self.h).decode()}")
+
+    def set_stream(self, stream_handle: Optional[int]):
+        self.check(self.lib.pba_ctx_set_stream(self.h, C.c_void_p(stream_handle or 0)), "set_stream")
+
+    def sync(self):
+        self.check(self.lib.pba_ctx_sync(self.h), "sync")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, mhz, hbm = C.c_int(), C.c_int(), C.c_uint64()
+        self.check(self.lib.pba_ctx_device_info(self.h, name, 256, C.byref(ncu), C.byref(mhz), C.byref(hbm)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "clock_mhz": mhz.value, "hbm_bytes": hbm.value}
+
+    # -- sequence sets
+    def seqs_from_text(self, text: np.ndarray, offsets: np.ndarray, strict_acgt: bool = False) -> "SeqSet":
+        text = np.ascontiguousarray(text, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        h = C.c_void_p()
+        self.check(self.lib.pba_seqs_from_text(self.h, _ptr(text), _ptr(offsets), offsets.size - 1,
+                                               int(strict_acgt), C.byref(h)), "seqs_from_text")
+        return SeqSet(self, h)
+
+    def seqs_from_list(self, seqs: Sequence[bytes], strict_acgt: bool = False) -> "SeqSet":
+        return self.seqs_from_text(*concat(seqs), strict_acgt=strict_acgt)
+
+    def seqs_from_device_text(self, d_text_ptr: int, d_offsets_ptr: int, n: int, total_bytes: int,
+                              max_len: int) -> "SeqSet":
+        h = C.c_void_p()
+        self.check(self.lib.pba_seqs_from_device_text(self.h, C.c_void_p(d_text_ptr), C.c_void_p(d_offsets_ptr), n,
+                                                      total_bytes, max_len, C.byref(h)), "seqs_from_device_text")
+        return SeqSet(self, h)
+
+    def seqs_from_records(self, file: bytes, min_excl: int = 500, max_excl: int = 20000) -> "SeqSet":
+        buf = np.frombuffer(file, np.uint8)
+        h = C.c_void_p()
+        self.check(self.lib.pba_seqs_from_records(self.h, _ptr(buf), len(file), min_excl, max_excl, C.byref(h)),
+                   "seqs_from_records")
+        return SeqSet(self, h)
+
+    # -- index
+    def index_build(self, target: "SeqSet", seq: int, mask: int, mode: int = PBA_INDEX_ALL) -> "SeedIndex":
+        h = C.c_void_p()
+        self.check(self.lib.pba_index_build(self.h, target.h, seq, mask, mode, C.byref(h)), "index_build")
+        return SeedIndex(self, h)
+
+    # -- alignment
+    def align_batch(self, A: "SeqSet", B: "SeqSet", pairs: np.ndarray, R: float, maxn: int = 0, maxm: int = 0,
+                    kernel: int = PBA_KERNEL_AUTO) -> np.ndarray:
+        pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+        out = np.zeros(pairs.size, RESULT_DTYPE)
+        self.check(self.lib.pba_align_batch(self.h, A.h, B.h, _ptr(pairs), pairs.size, R, maxn, maxm, kernel,
+                                            _ptr(out)), "align_batch")
+        return out
+
+    def align_text(self, a: bytes, b: bytes, R: float, a_fwd: bool = True, b_fwd: bool = True, maxn: int = 0,
+                   maxm: int = 0) -> np.ndarray:
+        """a/b hold the accessor's elements in memory order; a backward accessor starts at the last byte."""
+        abuf = np.frombuffer(a + b"\0", np.uint8)
+        bbuf = np.frombuffer(b + b"\0", np.uint8)
+        pa = abuf.ctypes.data + (0 if a_fwd or not a else len(a) - 1)
+        pb = bbuf.ctypes.data + (0 if b_fwd or not b else len(b) - 1)
+        out = np.zeros(1, RESULT_DTYPE)
+        self.check(self.lib.pba_align_text(self.h, C.c_void_p(pa), int(a_fwd), len(a), C.c_void_p(pb), int(b_fwd),
+                                           len(b), R, maxn, maxm, _ptr(out)), "align_text")
+        return out[0]
+
+    # -- drivers
+    def locate(self, ix: "SeedIndex", target: "SeqSet", target_seq: int, reads: "SeqSet", R: float,
+               trials: int = 50, min_len: int = 500, maxn: int = 0, maxm: int = 0, kernel: int = PBA_KERNEL_AUTO):
+        rows = np.zeros(max(reads.count, 1), LOC_ROW_DTYPE)
+        stats = PbaLocStats()
+        self.check(self.lib.pba_locate(self.h, ix.h, target.h, target_seq, reads.h, R, trials, min_len, maxn, maxm,
+                                       kernel, _ptr(rows), C.byref(stats)), "locate")
+        return rows[:reads.count], {n: getattr(stats, n) for n, _ in PbaLocStats._fields_}
+
+    def spaced_round(self, ix: "SeedIndex", ref: "SeqSet", ref_seq: int, reads: "SeqSet", R: float,
+                     max_trial: int = 32, overlap_min: int = 64, buggy_seed_at: bool = False,
+                     kernel: int = PBA_KERNEL_AUTO) -> np.ndarray:
+        rows = np.zeros(max(reads.count, 1), SS_ROW_DTYPE)
+        self.check(self.lib.pba_spaced_round(self.h, ix.h, ref.h, ref_seq, reads.h, R, max_trial, overlap_min,
+                                             int(buggy_seed_at), kernel, _ptr(rows)), "spaced_round")
+        return rows[:reads.count]
+
+
+class SeqSet:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.pba_seqs_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    @property
+    def count(self) -> int:
+        return self.ctx.lib.pba_seqs_count(self.h)
+
+    @property
+    def max_len(self) -> int:
+        return self.ctx.lib.pba_seqs_max_len(self.h)
+
+    @property
+    def packed_bytes(self) -> int:
+        return self.ctx.lib.pba_seqs_packed_bytes(self.h)
+
+    def lengths(self) -> np.ndarray:
+        out = np.zeros(max(self.count, 1), np.uint32)
+        self.ctx.check(self.ctx.lib.pba_seqs_lengths(self.h, _ptr(out), self.count))
+        return out[:self.count]
+
+    def get_text(self, i: int) -> bytes:
+        ln = int(self.lengths()[i])
+        buf = C.create_string_buffer(ln + 1)
+        self.ctx.check(self.ctx.lib.pba_seqs_get_text(self.ctx.h, self.h, i, buf, ln + 1), "get_text")
+        return buf.raw[:ln]
+
+
+class SeedIndex:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.pba_index_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    @property
+    def entries(self) -> int:
+        return self.ctx.lib.pba_index_entries(self.h)
+
+    @property
+    def visited(self) -> int:
+        return self.ctx.lib.pba_index_visited(self.h)
+
+    def dump(self):
+        n = self.entries
+        keys = np.zeros(max(n, 1), np.uint32)
+        pos = np.zeros(max(n, 1), np.int32)
+        got = C.c_uint64()
+        self.ctx.check(self.ctx.lib.pba_index_dump(self.ctx.h, self.h, _ptr(keys), _ptr(pos), n, C.byref(got)),
+                       "index_dump")
+        return keys[:n], pos[:n]
+
+    def find(self, keys: np.ndarray):
+        keys = np.ascontiguousarray(keys, np.uint32)
+        off = np.zeros(keys.size + 1, np.uint64)
+        lib, c = self.ctx.lib, self.ctx
+        c.check(lib.pba_index_find(c.h, self.h, _ptr(keys), keys.size, _ptr(off), None, 0), "index_find")
+        total = int(off[-1])
+        pos = np.zeros(max(total, 1), np.int32)
+        c.check(lib.pba_index_find(c.h, self.h, _ptr(keys), keys.size, _ptr(off), _ptr(pos), total), "index_find")
+        return off, pos[:total]

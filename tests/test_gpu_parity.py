@@ -1,0 +1,229 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against (1) the golden vectors the
+reference itself produced and (2) the CPU oracle on the same seeded inputs.  Bit-exact: seed-hit
+sets, hit order, integer scores and coordinates.  Needs a real MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from conftest import GOLD, MASK_PAT, gold_json, gold_npz
+from pacbioassembly_amd import engine as eng
+from pacbioassembly_amd.engine import (PAIR_DTYPE, PBA_INDEX_ALL, PBA_INDEX_HEAD_TAIL, PBA_KERNEL_BITVEC,
+                                       PBA_KERNEL_ROWSWEEP, PbaError)
+from test_oracle_golden import (check_locator_rows, index_digest, index_inputs, locator_inputs, spaced_inputs)
+
+pytestmark = pytest.mark.gpu
+KERNELS = [PBA_KERNEL_ROWSWEEP, PBA_KERNEL_BITVEC]
+
+
+def c2i_text(b: bytes) -> bytes:
+    return bytes(c if c in b"ACG" else ord("T") for c in b)
+
+
+# ----------------------------------------------------------------------------- sequence sets
+def test_seqs_pack_roundtrip(ctx):
+    seqs = [b"ACGTGTCATCGGATCAACCGGTT", b"", b"A", b"ACGTN", b"acgtNNNN", b"T" * 17, b"G" * 64, b"ACGT" * 1000 + b"AC"]
+    s = ctx.seqs_from_list(seqs)
+    assert s.count == len(seqs) and s.max_len == 4002
+    assert s.lengths().tolist() == [len(x) for x in seqs]
+    for i, x in enumerate(seqs):
+        assert s.get_text(i) == c2i_text(x)          # C2I: anything but A,C,G packs as 3 (dna_seq.h:21)
+    with pytest.raises(PbaError) as e:
+        ctx.seqs_from_list([b"ACGT", b"ACNT"], strict_acgt=True)
+    assert e.value.status == -6
+    ctx.seqs_from_list([b"ACGT", b"TTTT"], strict_acgt=True)
+
+
+def test_seqs_from_device_text_matches_host_path(ctx):
+    import torch
+    g = eng.synth_genome(3, 5000)
+    reads, offs, _ = eng.synth_reads(4, g, 50, 777)
+    d_text = torch.from_numpy(reads.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    s1 = ctx.seqs_from_device_text(d_text.data_ptr(), d_offs.data_ptr(), 50, reads.size, 777)
+    s2 = ctx.seqs_from_text(reads, offs)
+    for i in (0, 1, 17, 49):
+        assert s1.get_text(i) == s2.get_text(i) == reads[int(offs[i]):int(offs[i + 1])].tobytes()
+
+
+def test_seqs_from_records(ctx):
+    lines = open(f"{GOLD}/real_align.txt").read().split()
+    img = b"".join(eng.text2bin(l.encode()) for l in lines)
+    s = ctx.seqs_from_records(img, 500, 20000)       # spaced_seed.cpp:334 keeps 500 < len < 20000
+    keep = [l for l in lines if 500 < len(l) < 20000]
+    assert s.count == len(keep)
+    for i, l in enumerate(keep):
+        assert s.get_text(i) == l.encode()
+    assert ctx.seqs_from_records(img, 0, 1 << 30).count == 12
+
+
+# ----------------------------------------------------------------------------- seed index
+def test_index_golden(ctx, oracle):
+    g = gold_json("index.json")
+    b = g["ref_test_basic"]                          # test/ref_test.cpp:119-128
+    s = ctx.seqs_from_list([b["text"].encode()])
+    ix = ctx.index_build(s, 0, b["mask"], PBA_INDEX_HEAD_TAIL)
+    k, p = ix.dump()
+    assert k.tolist() == b["keys"] and p.tolist() == b["pos"] and ix.visited == b["rv"]
+    assert len(set(k.tolist())) == b["nkeys"] == len(b["text"]) - 15 - 1
+    for c in g["cases"]:
+        text = index_inputs(c)
+        s = ctx.seqs_from_list([b"ACGT" * 5, text])  # index sequence 1 of a set, not 0
+        mode = PBA_INDEX_ALL if c["mode"] == "all" else PBA_INDEX_HEAD_TAIL
+        ix = ctx.index_build(s, 1, c["mask"], mode)
+        k, p = ix.dump()
+        assert ix.entries == c["n"] == k.size, c["name"]
+        assert index_digest(k, p) == c["sha256"], c["name"]
+        if c["mode"] == "head_tail":
+            assert ix.visited == c["rv"] and len(np.unique(k)) == c["nkeys"], c["name"]
+        # hash_table::find for present, absent and zero keys, in list order
+        ok, op, _, _ = oracle.index(text, c["mask"], c["mode"])
+        rng = np.random.RandomState(7)
+        probe = np.concatenate([ok[rng.randint(0, max(ok.size, 1), 200)] if ok.size else np.zeros(0, np.uint32),
+                                rng.randint(0, 2 ** 32, 50, dtype=np.uint64).astype(np.uint32) & np.uint32(c["mask"]),
+                                np.array([0, 0xFFFFFFFF], np.uint32)]).astype(np.uint32)
+        off, pos = ix.find(probe)
+        for q, key in enumerate(probe):
+            want = op[ok == key].tolist() if key else []
+            assert pos[int(off[q]):int(off[q + 1])].tolist() == want, (c["name"], hex(int(key)))
+
+
+# ----------------------------------------------------------------------------- banded DP
+def check_result(got, exp, tag):
+    assert int(got["rc"]) == exp["rc"], (tag, int(got["rc"]), exp)
+    for k in ("len_a", "len_b", "max_dst"):
+        assert int(got[k]) == exp[k], (tag, k)
+    if exp["rc"] >= 0:
+        for k in ("cost", "matlen_a", "matlen_b"):
+            assert int(got[k]) == exp[k], (tag, k, int(got[k]), exp)
+
+
+def test_align_text_golden(ctx):
+    """Raw-byte semantics (seq_aligner.h:136), every golden case incl. the reference's own KATs."""
+    for c in gold_json("align_kat.json"):
+        got = ctx.align_text(c["a"].encode("latin1"), c["b"].encode("latin1"), c["R"], c["a_fwd"], c["b_fwd"])
+        check_result(got, c["exp"], c["tag"])
+
+
+def pairs_for(cases):
+    seqs, pairs = [], []
+    for c in cases:
+        a, b = c["a"].encode(), c["b"].encode()
+        ia, ib = len(seqs), len(seqs) + 1
+        seqs += [a, b]
+        fl = (0 if c["a_fwd"] else 1) | (0 if c["b_fwd"] else 2)
+        pairs.append((ia, 0 if c["a_fwd"] or not a else len(a) - 1, len(a), ib,
+                      0 if c["b_fwd"] or not b else len(b) - 1, len(b), fl))
+    return seqs, np.array(pairs, PAIR_DTYPE)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_align_batch_golden(ctx, kernel):
+    """Packed 2-bit path, both kernels, on every ACGT-only golden case, grouped by R."""
+    cases = [c for c in gold_json("align_kat.json") if set(c["a"] + c["b"]) <= set("ACGT")]
+    assert len(cases) > 280
+    for R in sorted({c["R"] for c in cases}):
+        sub = [c for c in cases if c["R"] == R]
+        seqs, pairs = pairs_for(sub)
+        S = ctx.seqs_from_list(seqs, strict_acgt=True)
+        out = ctx.align_batch(S, S, pairs, R, kernel=kernel)
+        for c, got in zip(sub, out):
+            check_result(got, c["exp"], (c["tag"], kernel))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_align_size_guard(ctx, kernel):
+    """seq_aligner.h:104-107: len_a >= MAXN+MAXM or max_dst >= MAXM -> -1."""
+    a = b"ACGT" * 30
+    S = ctx.seqs_from_list([a, a])
+    pr = np.array([(0, 0, 120, 1, 0, 120, 0)], PAIR_DTYPE)
+    assert int(ctx.align_batch(S, S, pr, 0.3, maxn=100, maxm=30, kernel=kernel)[0]["rc"]) == -1   # max_dst=37 >= 30
+    assert int(ctx.align_batch(S, S, pr, 0.3, maxn=60, maxm=50, kernel=kernel)[0]["rc"]) == -1    # len_a=120 >= 110
+    assert int(ctx.align_batch(S, S, pr, 0.3, maxn=100, maxm=40, kernel=kernel)[0]["rc"]) == 120
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_align_random_vs_oracle(ctx, oracle, kernel):
+    """Seeded synthetic pairs at sizes the oracle finishes in seconds: true overlaps, false hits,
+    both directions, a longer than b and b longer than a, R in {0.15, 0.30}."""
+    g = eng.synth_genome(77, 60000)
+    reads, offs, starts = eng.synth_reads(78, g, 48, 2500)
+    seqs = [g.tobytes()] + [reads[int(offs[r]):int(offs[r + 1])].tobytes() for r in range(48)]
+    S = ctx.seqs_from_list(seqs, strict_acgt=True)
+    rng = np.random.RandomState(5)
+    pairs = []
+    for r in range(48):
+        tp, rs = int(starts[r]), r + 1
+        j = int(rng.randint(0, 40))
+        pairs.append((rs, j, 2500 - j, 0, tp + j, 60000 - tp - j, 0))              # true locus, locator shape
+        p = int(rng.randint(0, 50000))
+        pairs.append((rs, j, 2500 - j, 0, p, 60000 - p, 0))                         # false locus
+        ln = int(rng.randint(300, 2000))
+        pairs.append((0, tp, min(60000 - tp, ln + 900), rs, 0, ln, 0))              # a longer than b (SURVEY B4 shape)
+        k = int(rng.randint(600, 2400))
+        pairs.append((rs, k, k + 1, 0, tp + k, tp + k + 1, 3))                      # both backward
+        pairs.append((rs, 0, 2500, rs, 0, 2500, 0))                                 # identical
+    arr = np.array(pairs, PAIR_DTYPE)
+
+    def elems(seq, pos, ln, back):
+        return seqs[seq][pos - ln + 1:pos + 1] if back else seqs[seq][pos:pos + ln]
+
+    for R in (0.30, 0.15):
+        out = ctx.align_batch(S, S, arr, R, kernel=kernel)
+        n_ok = 0
+        for pr, got in zip(pairs, out):
+            sa, pa, la, sb, pb, lb, fl = pr
+            exp = oracle.align(elems(sa, pa, la, fl & 1), elems(sb, pb, lb, fl & 2), R, not (fl & 1), not (fl & 2))
+            check_result(got, exp, (R, pr, kernel))
+            n_ok += exp["rc"] >= 0
+        assert n_ok >= 48          # the test is not vacuous: plenty of successful alignments
+
+
+# ----------------------------------------------------------------------------- drivers
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["cfg1_R30", "cfg1_R15", "cfg1_pacbio", "short_mix", "r15k_R30", "r15k_R15"])
+def test_locate_golden(ctx, name, kernel):
+    """locator.cpp:70-92 end to end: same rows (found, j, pos, cost, len-j, matlen) and the same
+    number of candidate pairs per read as the reference."""
+    meta = {m["name"]: m for m in gold_json("locator.json")}[name]
+    want = gold_npz("locator.npz")[name]
+    g, reads, offs = locator_inputs(meta)
+    T = ctx.seqs_from_list([g.tobytes()], strict_acgt=True)
+    Rd = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    ix = ctx.index_build(T, 0, meta["mask"], PBA_INDEX_ALL)
+    rows, st = ctx.locate(ix, T, 0, Rd, meta["R"], meta["trials"], meta["min_len"], kernel=kernel)
+    check_locator_rows(rows, want, meta["columns"], name)
+    for k, v in meta["stats"].items():
+        assert st[k] == v, (name, k, st)
+
+
+def test_locate_cells_match_oracle(ctx, oracle):
+    meta = {m["name"]: m for m in gold_json("locator.json")}["cfg1_pacbio"]
+    g, reads, offs = locator_inputs(meta)
+    T = ctx.seqs_from_list([g.tobytes()])
+    Rd = ctx.seqs_from_text(reads, offs)
+    ix = ctx.index_build(T, 0, meta["mask"], PBA_INDEX_ALL)
+    _, st = ctx.locate(ix, T, 0, Rd, meta["R"], meta["trials"], meta["min_len"], kernel=PBA_KERNEL_ROWSWEEP)
+    _, so = oracle.locator(g, meta["mask"], meta["R"], reads, offs, meta["trials"], meta["min_len"], nthreads=4)
+    assert st == so
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["ss_30k", "ss_50k", "ss_12k"])
+def test_spaced_round_golden(ctx, name, kernel):
+    """spaced_seed.cpp:420-437 (locked round) incl. seed_at's pos%4==0 behaviour."""
+    meta = {m["name"]: m for m in gold_json("spaced.json")}[name]
+    want = gold_npz("spaced.npz")[name]
+    g, file, rec_offs = spaced_inputs(meta, eng.text2bin)
+    Rf = ctx.seqs_from_list([g.tobytes()])
+    Rd = ctx.seqs_from_records(file, 0, 1 << 30)
+    assert Rd.count == meta["n_reads"]
+    ix = ctx.index_build(Rf, 0, meta["mask"], PBA_INDEX_HEAD_TAIL)
+    rows = ctx.spaced_round(ix, Rf, 0, Rd, meta["R"], meta["max_trial"], meta["overlap_min"], buggy_seed_at=True,
+                            kernel=kernel)
+    cols = meta["columns"]
+    for ci, col in enumerate(cols):
+        if col in ("dir", "ref_pos", "cost", "matlen_a", "matlen_b"):
+            sel = want[:, cols.index("found")] == 1
+            assert (rows[col][sel] == want[sel, ci]).all(), (name, col)
+        else:
+            assert (rows[col] == want[:, ci]).all(), (name, col)

@@ -1,0 +1,150 @@
+"""Pin oracle/pba_oracle.c (the CPU restatement) to the golden vectors produced by the reference
+itself (tests/golden/make_golden.py) and to the reference's own test KATs.  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, gold_json, gold_npz
+from pacbioassembly_amd import engine as eng
+
+RES_KEYS = ("rc", "cost", "matlen_a", "matlen_b", "len_a", "len_b", "max_dst", "nedit")
+
+
+def test_codec(oracle):
+    g = gold_json("codec.json")
+    for w, code in g["encode"]:
+        assert oracle.encode(w.encode()) == code
+    for c, v in g["c2i"]:
+        assert oracle.lib.orc_c2i(c) == v
+    rec = oracle.text2bin(g["seed_at_text"].encode())
+    for pos, want in g["seed_at"]:
+        assert oracle.seed_at(rec, pos) == want
+    for pat, m in g["masks"]:
+        assert oracle.mask_from_pattern(pat) == m
+    for s, hexrec, back in g["text2bin"]:
+        assert oracle.text2bin(s.encode()).hex() == hexrec
+        assert oracle.bin2text(bytes.fromhex(hexrec)).decode() == back
+
+
+def check_align_case(got, exp, tag):
+    assert got["rc"] == exp["rc"], tag
+    for k in ("len_a", "len_b", "max_dst"):
+        assert got[k] == exp[k], (tag, k)
+    if exp["rc"] >= 0:
+        for k in ("cost", "matlen_a", "matlen_b"):
+            assert got[k] == exp[k], (tag, k)
+
+
+def test_align_kats(oracle):
+    cases = gold_json("align_kat.json")
+    assert len(cases) > 300
+    for c in cases:
+        got = oracle.align(c["a"].encode("latin1"), c["b"].encode("latin1"), c["R"], c["a_fwd"], c["b_fwd"],
+                           want_ops=True)
+        check_align_case(got, c["exp"], c["tag"])
+        if c["exp"]["rc"] >= 0:
+            assert got["nedit"] == c["exp"]["nedit"], c["tag"]
+            assert (int(got["ops"][0]) if got["nedit"] else 0) == c["exp"]["first_op"], c["tag"]
+
+
+def test_aligner_test_expectations(oracle):
+    """test/aligner_test.cpp:44-117, the assertions as the reference states them."""
+    ref, s1, s2, s3 = b"ACGTAACCGGTT", b"CGTAAGC", b"GTAACGGGTTAA", b"TCGTAAC"
+    r = oracle.align(s1[:6], ref[:7], 0.3); assert 6 <= r["rc"] <= 7 and r["cost"] == 2
+    r = oracle.align(s1[:7], ref[:8], 0.3); assert r["rc"] == 7 and r["cost"] == 2
+    r = oracle.align(s3[:7], ref[:8], 0.3); assert r["rc"] == 7 and r["cost"] == 1
+    r = oracle.align(s1[:7], ref[1:8], 0.3, False, False); assert r["rc"] == 7 and r["cost"] == 1
+    r = oracle.align(s2, ref[2:12], 0.3); assert r["rc"] == 10 and r["cost"] == 1
+    r = oracle.align(ref[1:10], ref[:10], 0.3, want_ops=True)
+    assert r["rc"] == 10 and r["nedit"] == 10 and r["ops"][0] == 2 and r["cost"] == 1      # INSERT
+    r = oracle.align(ref[:10], ref[1:10], 0.3, want_ops=True)
+    assert r["rc"] == 9 and r["nedit"] == 10 and r["ops"][0] == 3 and r["cost"] == 1       # DELETE
+    lines = open(f"{GOLD}/real_align.txt").read().split()
+    assert oracle.align(lines[1].encode(), lines[0].encode(), 0.3, False, False)["rc"] > 0
+    assert oracle.align(lines[3].encode(), lines[2].encode(), 0.3)["rc"] == -1
+
+
+def index_inputs(case):
+    if "seed" in case:
+        return eng.synth_genome(case["seed"], case["len"]).tobytes()
+    return (case["text_unit"].encode() * (case["len"] // len(case["text_unit"]) + 1))[:case["len"]]
+
+
+def index_digest(k, p):
+    return hashlib.sha256(k.astype("<u4").tobytes() + p.astype("<i4").tobytes()).hexdigest()
+
+
+def test_index(oracle):
+    g = gold_json("index.json")
+    arrays = gold_npz("index.npz")
+    b = g["ref_test_basic"]                         # test/ref_test.cpp:119-128
+    k, p, rv, nk = oracle.index(b["text"].encode(), b["mask"], "head_tail")
+    assert k.tolist() == b["keys"] and p.tolist() == b["pos"] and rv == b["rv"] and nk == b["nkeys"]
+    sz = len(b["text"])
+    assert nk == sz - 15 - 1 and sorted(p.tolist()) == list(range(sz - 16))
+    for c in g["cases"]:
+        k, p, rv, nk = oracle.index(index_inputs(c), c["mask"], "all" if c["mode"] == "all" else "head_tail")
+        assert k.size == c["n"], c["name"]
+        assert index_digest(k, p) == c["sha256"], c["name"]
+        if c["mode"] == "head_tail":
+            assert rv == c["rv"] and nk == c["nkeys"], c["name"]
+        if c["name"] + "_keys" in arrays:
+            assert (k == arrays[c["name"] + "_keys"]).all() and (p == arrays[c["name"] + "_pos"]).all()
+
+
+def locator_inputs(m):
+    g = eng.synth_genome(m["genome_seed"], m["genome_len"])
+    reads, offs, _ = eng.synth_reads(m["reads_seed"], g, m["n_reads"], m["read_len"], *m["err"])
+    if m["name"] == "short_mix":
+        n, rl = m["n_reads"], m["read_len"]
+        cut = [(int(offs[i]), int(offs[i]) + (300 if i % 3 == 0 else rl)) for i in range(n)]
+        reads = np.concatenate([reads[a:b] for a, b in cut])
+        offs = np.concatenate([[0], np.cumsum([b - a for a, b in cut])]).astype(np.uint64)
+    return g, reads, offs
+
+
+def check_locator_rows(rows, want, cols, name):
+    for ci, col in enumerate(cols):
+        if col in ("cost", "matlen_a", "matlen_b", "seglen", "pos", "j"):
+            sel = want[:, cols.index("found")] == 1
+            assert (rows[col][sel] == want[sel, ci]).all(), (name, col)
+        else:
+            assert (rows[col] == want[:, ci]).all(), (name, col)
+
+
+@pytest.mark.parametrize("name", ["cfg1_R30", "cfg1_R15", "cfg1_pacbio", "short_mix", "r15k_R30", "r15k_R15"])
+def test_locator(oracle, name):
+    meta = {m["name"]: m for m in gold_json("locator.json")}[name]
+    want = gold_npz("locator.npz")[name]
+    g, reads, offs = locator_inputs(meta)
+    rows, st = oracle.locator(g, meta["mask"], meta["R"], reads, offs, meta["trials"], meta["min_len"], nthreads=8)
+    check_locator_rows(rows, want, meta["columns"], name)
+    for k, v in meta["stats"].items():
+        assert st[k] == v, (name, k)
+
+
+def spaced_inputs(m, text2bin):
+    g = eng.synth_genome(m["genome_seed"], m["genome_len"])
+    reads, offs, _ = eng.synth_reads(m["reads_seed"], g, m["n_reads"], m["read_len"])
+    rl = m["read_len"]
+    file = b"".join(text2bin(reads[int(offs[i]):int(offs[i + 1])].tobytes()) for i in range(m["n_reads"]))
+    rec_offs = np.array([i * (4 + (rl + 3) // 4) for i in range(m["n_reads"])], np.uint64)
+    return g, file, rec_offs
+
+
+@pytest.mark.parametrize("name", ["ss_30k", "ss_50k", "ss_12k"])
+def test_spaced_round(oracle, name):
+    meta = {m["name"]: m for m in gold_json("spaced.json")}[name]
+    want = gold_npz("spaced.npz")[name]
+    g, file, rec_offs = spaced_inputs(meta, oracle.text2bin)
+    rows = oracle.spaced_round(g.tobytes(), meta["mask"], meta["R"], file, rec_offs, meta["max_trial"],
+                               meta["overlap_min"], buggy=True, nthreads=8)
+    cols = meta["columns"]
+    for ci, col in enumerate(cols):
+        if col in ("dir", "ref_pos", "cost", "matlen_a", "matlen_b"):
+            sel = want[:, cols.index("found")] == 1
+            assert (rows[col][sel] == want[sel, ci]).all(), (name, col)
+        else:
+            assert (rows[col] == want[:, ci]).all(), (name, col)
+    assert int(rows["found"].sum()) == meta["found"]
