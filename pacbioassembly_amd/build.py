@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         "-Wall", "-Wno-unused-function",
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         "-o", LIB,
-    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+    ] + os.environ.get("PBA_EXTRA_CFLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -67,14 +67,19 @@ struct BaseStream {
 };
 
 __device__ __forceinline__ uint32_t wave_ror1(uint32_t v) {
-    // lane i receives lane (i-1) mod 64: DPP wave_ror:1 (0x13C), available on gfx9-family ISAs
+    // lane i receives lane (i-1) mod 64
+#ifdef PBA_BV_USE_BPERMUTE
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63) + 63) & 63) << 2), (int)v);
+#else
+    // DPP wave_ror:1 (0x13C), available on gfx9-family ISAs
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
+#endif
 }
 
 // One sweep with half-width w.  Returns 0 when all diagonal checks pass (then best / bestj hold the
 // goal-row minimum and its column), else the first failing row.
 template <int NB>
-__device__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int w, double R,
+__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int w, double R,
                            int &best_out, int &bestj_out) {
     constexpr int RB = 32 * NB;                 // rows per superblock
     const int lane = threadIdx.x & (PBA_WAVE - 1);
@@ -194,43 +199,42 @@ __device__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &c
     return 0;
 }
 
-__device__ __noinline__ int bitvec_pass_any(int nb, const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n,
-                                            int w, double R, int &best, int &bestj) {
-    switch (nb) {
-        case 1: return bitvec_pass<1>(rowsF, m, colsF, n, w, R, best, bestj);
-        case 2: return bitvec_pass<2>(rowsF, m, colsF, n, w, R, best, bestj);
-        case 3: return bitvec_pass<3>(rowsF, m, colsF, n, w, R, best, bestj);
-        case 4: return bitvec_pass<4>(rowsF, m, colsF, n, w, R, best, bestj);
-        case 6: return bitvec_pass<6>(rowsF, m, colsF, n, w, R, best, bestj);
-        default: return bitvec_pass<8>(rowsF, m, colsF, n, w, R, best, bestj);
-    }
-}
-
 // true when the bit-vector kernel can take a pair with this max_dst (else: row sweep)
 __device__ __host__ inline bool bitvec_supports(int max_dst) { return bv_nb_for(max_dst) != 0; }
+// first-pass half width for a given max_dst
+__device__ __host__ inline int bv_first_w(int md) {
+    const int w = (md / 2 > (int)((long long)md * PBA_BV_BAND_NUM / PBA_BV_BAND_DEN)
+                       ? md / 2 : (int)((long long)md * PBA_BV_BAND_NUM / PBA_BV_BAND_DEN)) + 1;
+    return w > md ? md : w;
+}
 
+#define PBA_RC_UNCERTIFIED (-3)   // narrow pass could not certify the goal row: re-run with full_band
+
+// One pair.  NB is chosen by the host from the largest max_dst in the launch (any NB >= the pair's own
+// need is valid).  full_band = false runs the narrow first pass and reports PBA_RC_UNCERTIFIED when the
+// goal row cannot be certified; the host then re-launches those pairs with full_band = true.
+// There is deliberately no device function call in here: everything inlines into the kernel.
 // lds: >= 256 bytes (only the m <= 10 corner uses it, through the row sweep)
-__device__ void align_bitvec(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R, int maxn,
-                             int maxm, uint16_t *lds, int lds_cells, AlnOut &o) {
+template <int NB>
+__device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
+                                             int maxn, int maxm, bool full_band, uint16_t *lds, int lds_cells,
+                                             AlnOut &o) {
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
     if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return;      // seq_aligner.h:104-107
     const bool swap = len_a > len_b;            // the DP is symmetric under transposition: rows = shorter side
     const int m = swap ? len_b : len_a, n = swap ? len_a : len_b;
-    if (m <= 10 || !bitvec_supports(md)) {      // no diagonal check ever fires / band too wide for the array
+    if (m <= 10) {                              // no diagonal check ever fires: plain DP on a <= 23-cell band
         align_rowsweep(fa, la, fb, lb, R, maxn, maxm, lds, lds_cells, o);
         return;
     }
-    const PackedFetch &rowsF = swap ? fb : fa, &colsF = swap ? fa : fb;
-    int w = max(md / 2, (int)((long long)md * PBA_BV_BAND_NUM / PBA_BV_BAND_DEN)) + 1;
-    if (w > md) w = md;
+    const int w = full_band ? md : bv_first_w(md);
+    if (w > bv_max_w(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
+    const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
     int best = 0, bestj = 0;
-    for (;;) {
-        const int fr = bitvec_pass_any(bv_nb_for(w), rowsF, m, colsF, n, w, R, best, bestj);
-        if (fr) { o.fail_row = fr; return; }
-        if (w >= md || best <= w) break;        // goal row certified exact (header comment)
-        w = md;
-    }
+    const int fr = bitvec_pass<NB>(rowsF, m, colsF, n, w, R, best, bestj);
+    if (fr) { o.fail_row = fr; return; }
+    if (w < md && best > w) { o.rc = PBA_RC_UNCERTIFIED; return; }     // header comment: goal row not certified
     o.cost = best;
     o.matlen_a = swap ? bestj : m;
     o.matlen_b = swap ? m : bestj;

@@ -10,6 +10,7 @@
 #include <new>
 #include <vector>
 
+#include "align_bitvec.h"
 #include "align_rowsweep.h"
 #include "dev_common.h"
 #include "pba.h"
@@ -30,6 +31,7 @@ struct pba_seqs {
     pba_ctx *ctx;
     uint32_t n, max_len;
     uint64_t packed_bytes;   // packed payload resident in HBM (incl. alignment padding)
+    uint8_t *d_alloc;        // allocation; d_packed = d_alloc + kSlack
     uint8_t *d_packed;
     uint64_t *d_off;
     uint32_t *d_len;
@@ -64,7 +66,8 @@ static int ctx_fail(pba_ctx *ctx, int st, const char *what, hipError_t e) {
 // engine limits
 static const int kMaxSeqLen = 65000;            // u16 DP costs: D(i,j) <= max(i,j) < 65535
 static const int kRowSweepLdsCap = 96 * 1024;   // LDS bytes one wavefront may take for its band row
-static const size_t kSlack = 64;                // readable bytes after the last packed byte
+static const size_t kSlack = 1024;              // readable bytes before the first and after the last packed byte
+                                                // (the bit-vector kernel streams a few hundred bases past an accessor)
 
 // RAII for temporaries so early returns do not leak device memory
 struct DevBuf {
@@ -109,23 +112,29 @@ k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_of
 // ---------------------------------------------------------------------------------------------
 // kernels: alignment of explicit pairs
 // ---------------------------------------------------------------------------------------------
+// Every aligning kernel is a template on NB, the number of 32-row blocks a lane of the bit-vector
+// array holds (align_bitvec.h); NB = 0 is the row-sweep kernel.  The host picks NB per launch from
+// the widest band in the batch.  Nothing below calls a device function: the bodies inline.
 struct AlignCfg {
     double R;
     int maxn, maxm;
-    int row_cap;   // u16 cells of LDS per wavefront (row sweep)
-    int kernel;    // pba_kernel
+    int row_cap;     // u16 cells of LDS per wavefront
+    int full_band;   // bit-vector kernel: 0 = narrow first pass (may answer PBA_RC_UNCERTIFIED), 1 = reference band
 };
 
-template <class FA, class FB>
-__device__ __forceinline__ void align_dispatch(const FA &fa, int la, const FB &fb, int lb, const AlignCfg &cfg,
-                                               void *lds, AlnOut &o) {
-    align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o);
+template <int NB>
+__device__ __forceinline__ void align_dispatch(const PackedFetch &fa, int la, const PackedFetch &fb, int lb,
+                                               const AlignCfg &cfg, void *lds, AlnOut &o) {
+    if constexpr (NB == 0)
+        align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o);
+    else
+        align_bitvec<NB>(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds, cfg.row_cap, o);
 }
 
 __device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
     if ((threadIdx.x & (PBA_WAVE - 1)) == 0) {
         const bool ok = o.rc >= 0;
-        out->rc = ok ? o.rc : -1;
+        out->rc = ok ? o.rc : (o.rc == PBA_RC_UNCERTIFIED ? PBA_RC_UNCERTIFIED : -1);
         out->cost = ok ? o.cost : 0;
         out->matlen_a = ok ? o.matlen_a : 0;
         out->matlen_b = ok ? o.matlen_b : 0;
@@ -133,16 +142,19 @@ __device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
     }
 }
 
+// ids (nullable): the subset of pairs / reads to process (second, full-band launch)
+template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE)
-k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n, AlignCfg cfg, pba_result *out) {
+k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg,
+              pba_result *out) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const uint32_t q = blockIdx.x;
-    if (q >= n) return;
+    if (blockIdx.x >= n) return;
+    const uint32_t q = ids ? ids[blockIdx.x] : blockIdx.x;
     const pba_pair pr = pairs[q];
     PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
     PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
     AlnOut o;
-    align_dispatch(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
+    align_dispatch<NB>(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
     store_result(out + q, o);
 }
 
@@ -164,21 +176,29 @@ __device__ __forceinline__ long long pair_cells(const AlnOut &o) {
     return band_cells(o.len_b, o.max_dst, o.fail_row ? o.fail_row : o.len_a);
 }
 
+// per-read side outputs of k_locate
+struct LocAux {
+    long long cells;     // band cells the reference would evaluate for this read
+    int probe_hits;      // probes that found their key
+    int redo;            // 1: a pair came back PBA_RC_UNCERTIFIED, the read must be re-run at full band
+};
+
 // locator.cpp:70-92
+template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE)
-k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, uint32_t n_reads, int trials, int min_len,
-         AlignCfg cfg, pba_loc_row *rows, long long *stats /* probe hits, cells */) {
+k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *ids, uint32_t n, int trials,
+         int min_len, AlignCfg cfg, pba_loc_row *rows, LocAux *aux) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const uint32_t r = blockIdx.x;
-    if (r >= n_reads) return;
+    if (blockIdx.x >= n) return;
+    const uint32_t r = ids ? ids[blockIdx.x] : blockIdx.x;
     const int len = (int)Rd.len[r];
-    int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0;
+    int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0, redo = 0;
     long long ncell = 0;
     if (len >= min_len) {                                                   // locator.cpp:72
         const uint8_t *rseq = Rd.packed + Rd.off[r];
         const uint8_t *tsq = T.packed + T.off[tseq];
         const int clen = (int)T.len[tseq];
-        for (int j = 0; j < trials && j < len && !found; ++j) {             // locator.cpp:74
+        for (int j = 0; j < trials && j < len && !found && !redo; ++j) {    // locator.cpp:74
             const uint32_t key = window_key(rseq, (uint32_t)j, (uint32_t)len) & ix.mask;   // locator.cpp:75
             if (key == 0) continue;                                         // never inserted, locator.cpp:64
             uint32_t beg, cnt;
@@ -190,7 +210,8 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, uint32_t n_reads
                 PackedFetch fa{rseq, j, 1};                                 // a = read from j   (locator.cpp:78)
                 PackedFetch fb{tsq, pos, 1};                                // b = contig from pos (locator.cpp:80)
                 AlnOut o;
-                align_dispatch(fa, len - j, fb, clen - pos, cfg, lds, o);
+                align_dispatch<NB>(fa, len - j, fb, clen - pos, cfg, lds, o);
+                if (o.rc == PBA_RC_UNCERTIFIED) { redo = 1; break; }
                 ++npairs;
                 ncell += pair_cells(o);
                 if (o.rc > 0) {                                             // locator.cpp:82
@@ -204,8 +225,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, uint32_t n_reads
         pba_loc_row *row = rows + r;          // read / nseq are filled by the host
         row->found = found; row->j = fj; row->pos = fpos; row->cost = fcost;
         row->seglen = found ? len - fj : 0; row->matlen_a = fma; row->matlen_b = fmb; row->n_pairs = npairs;
-        if (nhit) atomicAdd((unsigned long long *)&stats[0], (unsigned long long)nhit);
-        if (ncell) atomicAdd((unsigned long long *)&stats[1], (unsigned long long)ncell);
+        aux[r].cells = ncell; aux[r].probe_hits = nhit; aux[r].redo = redo;
     }
 }
 
@@ -216,12 +236,13 @@ __device__ __forceinline__ uint32_t seed_at_dev(const uint8_t *payload, int pos,
 }
 
 struct SsState {
-    int found, dir, ref_pos, cost, ma, mb, ntrials, npairs;
+    int found, dir, ref_pos, cost, ma, mb, ntrials, npairs, redo;
 };
 
-__device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, int ref_len, const uint8_t *rseq, int slen,
-                                       int pos, int dir, int overlap_min, int buggy, const AlignCfg &cfg, void *lds,
-                                       SsState &st) {
+template <int NB>
+__device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, int ref_len, const uint8_t *rseq,
+                                       int slen, int pos, int dir, int overlap_min, int buggy, const AlignCfg &cfg,
+                                       void *lds, SsState &st) {
     if (pos < 0 || pos + 16 > slen) return false;   // the reference only keeps reads > 500 bases
     const uint32_t key = seed_at_dev(rseq, pos, (uint32_t)slen, buggy) & ix.mask;   // spaced_seed.cpp:265
     if (key == 0) return false;
@@ -240,7 +261,8 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, i
         PackedFetch fa{ref, r_off, fwd ? 1 : -1};                  // a = reference (ref_seq.h:264)
         PackedFetch fb{rseq, s_off, fwd ? 1 : -1};
         AlnOut o;
-        align_dispatch(fa, r_len, fb, s_len, cfg, lds, o);
+        align_dispatch<NB>(fa, r_len, fb, s_len, cfg, lds, o);
+        if (o.rc == PBA_RC_UNCERTIFIED) { st.redo = 1; return true; }
         ++st.npairs;
         if (o.rc < 0) continue;                                    // ref_seq.h:264
         if (o.matlen_a < overlap_min) continue;                    // ref_seq.h:265
@@ -250,32 +272,46 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, i
     return false;
 }
 
+template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE)
-k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, uint32_t n_reads, int max_trial,
-               int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows) {
+k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const uint32_t *ids, uint32_t n,
+               int max_trial, int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows, int *redo) {
     extern __shared__ __align__(16) uint8_t lds[];
-    const uint32_t r = blockIdx.x;
-    if (r >= n_reads) return;
+    if (blockIdx.x >= n) return;
+    const uint32_t r = ids ? ids[blockIdx.x] : blockIdx.x;
     const uint8_t *ref = Rf.packed + Rf.off[rseq_id];
     const int ref_len = (int)Rf.len[rseq_id];
     const uint8_t *rseq = Rd.packed + Rd.off[r];
     const int slen = (int)Rd.len[r];
-    SsState st = {0, 0, 0, 0, 0, 0, 0, 0};
+    SsState st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int fj = -1;
     for (int j = 0; j < max_trial; ++j) {                          // spaced_seed.cpp:424-426
-        if (ss_try(ix, ref, ref_len, rseq, slen, j, 1, overlap_min, buggy, cfg, lds, st) ||
-            ss_try(ix, ref, ref_len, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, lds, st)) {
+        if (ss_try<NB>(ix, ref, ref_len, rseq, slen, j, 1, overlap_min, buggy, cfg, lds, st) ||
+            ss_try<NB>(ix, ref, ref_len, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, lds, st)) {
             fj = j;
             break;
         }
     }
     if ((threadIdx.x & (PBA_WAVE - 1)) == 0) {
         pba_ss_row *row = rows + r;
-        row->read = (int32_t)r; row->found = st.found; row->j = fj; row->dir = st.dir; row->ref_pos = st.ref_pos;
-        row->cost = st.cost; row->matlen_a = st.ma; row->matlen_b = st.mb; row->n_trials = st.ntrials;
-        row->n_pairs = st.npairs;
+        row->read = (int32_t)r; row->found = st.found; row->j = st.found ? fj : -1; row->dir = st.dir;
+        row->ref_pos = st.ref_pos; row->cost = st.cost; row->matlen_a = st.ma; row->matlen_b = st.mb;
+        row->n_trials = st.ntrials; row->n_pairs = st.npairs;
+        redo[r] = st.redo;
     }
 }
+
+// NB -> template instantiation.  K(NB) must expand to a statement launching the kernel.
+#define PBA_DISPATCH_NB(nb, K) \
+    switch (nb) {              \
+        case 0: K(0); break;   \
+        case 1: K(1); break;   \
+        case 2: K(2); break;   \
+        case 3: K(3); break;   \
+        case 4: K(4); break;   \
+        case 6: K(6); break;   \
+        default: K(8); break;  \
+    }
 
 // ---------------------------------------------------------------------------------------------
 // host API: context
@@ -308,10 +344,10 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     // kernels that take more than the default 64 KB of dynamic LDS
     const int big = 160 * 1024;
     (void)hipFuncSetAttribute((const void *)k_part_sort, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void *)k_align_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_align_pairs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)k_align_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void *)k_locate, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute((const void *)k_spaced_round, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_locate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_spaced_round<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     *out = ctx;
     return PBA_OK;
 }
@@ -352,8 +388,9 @@ int pba_ctx_device_info(const pba_ctx *ctx, char *name, size_t cap, int *n_cu, i
 // ---------------------------------------------------------------------------------------------
 static int seqs_alloc(pba_ctx *ctx, pba_seqs *s, uint64_t packed_bytes) {
     s->packed_bytes = packed_bytes;
-    HIPCHK(hipMalloc((void **)&s->d_packed, packed_bytes + kSlack));
-    HIPCHK(hipMemsetAsync(s->d_packed, 0, packed_bytes + kSlack, ctx->stream));
+    HIPCHK(hipMalloc((void **)&s->d_alloc, packed_bytes + 2 * kSlack));
+    HIPCHK(hipMemsetAsync(s->d_alloc, 0, packed_bytes + 2 * kSlack, ctx->stream));
+    s->d_packed = s->d_alloc + kSlack;
     HIPCHK(hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (s->n + 1)));
     HIPCHK(hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (s->n + 1)));
     HIPCHK(hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * s->n, hipMemcpyHostToDevice, ctx->stream));
@@ -364,7 +401,7 @@ static int seqs_alloc(pba_ctx *ctx, pba_seqs *s, uint64_t packed_bytes) {
 void pba_seqs_destroy(pba_seqs *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    if (s->d_packed) (void)hipFree(s->d_packed);
+    if (s->d_alloc) (void)hipFree(s->d_alloc);
     if (s->d_off) (void)hipFree(s->d_off);
     if (s->d_len) (void)hipFree(s->d_len);
     delete s;
@@ -375,7 +412,7 @@ static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff
                      int strict, pba_seqs **out) {
     pba_seqs *s = new (std::nothrow) pba_seqs();
     if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
-    s->ctx = ctx; s->n = n; s->max_len = 0; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->ctx = ctx; s->n = n; s->max_len = 0; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
     s->h_off.resize(n + 1); s->h_len.resize(n + 1);
     uint64_t pk = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -451,7 +488,7 @@ int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, ui
     pba_open_binary(file, file_len, min_excl, max_excl, recs.data(), kept, nullptr);
     pba_seqs *s = new (std::nothrow) pba_seqs();
     if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
-    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
     s->h_off.resize(kept + 1); s->h_len.resize(kept + 1);
     for (size_t i = 0; i < kept; ++i) {
         uint32_t L;
@@ -466,8 +503,9 @@ int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, ui
     // seed_at's byte-offset reads to stay inside the allocation and read zeros
     const uint64_t slack = 65536;
     s->packed_bytes = file_len;
-    hipError_t e = hipMalloc((void **)&s->d_packed, file_len + slack);
-    if (e == hipSuccess) e = hipMemsetAsync(s->d_packed, 0, file_len + slack, ctx->stream);
+    hipError_t e = hipMalloc((void **)&s->d_alloc, file_len + slack + kSlack);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_alloc, 0, file_len + slack + kSlack, ctx->stream);
+    if (e == hipSuccess) s->d_packed = s->d_alloc + kSlack;
     if (e == hipSuccess && file_len) e = hipMemcpyAsync(s->d_packed, file, file_len, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (kept + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (kept + 1));
@@ -677,16 +715,30 @@ static int max_dst_of(int la, int lb, double R) {      // seq_aligner.h:94-102
     return 1 + (int)((lb >= la ? la : lb) * R);
 }
 
-static int make_cfg(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int max_dst_max, AlignCfg *cfg, size_t *lds) {
+// Launch plan for a batch whose widest band is max_dst_max.
+struct Plan {
+    AlignCfg cfg;
+    size_t lds;
+    int nb1;     // first launch: 0 = row sweep, else bit-vector array with nb1 blocks per lane (narrow band)
+    int nb2;     // second launch (uncertified pairs only): bit-vector array at the reference band
+};
+
+static int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int max_dst_max, Plan *pl) {
     if (!(R > 0.0) || !(R < 1.0)) PBA_FAIL(PBA_E_INVALID, "R must be in (0,1)");
     if (kernel != PBA_KERNEL_AUTO && kernel != PBA_KERNEL_ROWSWEEP && kernel != PBA_KERNEL_BITVEC)
         PBA_FAIL(PBA_E_INVALID, "unknown kernel");
-    const long long W = 2ll * max_dst_max + 1;
+    const bool bv = kernel != PBA_KERNEL_ROWSWEEP && bitvec_supports(max_dst_max);
+    if (kernel == PBA_KERNEL_BITVEC && !bv) PBA_FAIL(PBA_E_TOOLONG, "band too wide for the bit-vector kernel");
+    // the bit-vector kernel needs LDS only for its m <= 10 corner (a 23-cell row at most); the row sweep
+    // needs the whole band row
+    const long long W = bv ? 127 : 2ll * max_dst_max + 1;
     const long long bytes = ((W * 2 + 15) / 16) * 16;
     if (bytes > kRowSweepLdsCap) PBA_FAIL(PBA_E_TOOLONG, "band row does not fit the per-wavefront LDS budget");
-    cfg->R = R; cfg->maxn = maxn; cfg->maxm = maxm; cfg->kernel = kernel;
-    cfg->row_cap = (int)(bytes / 2);
-    *lds = (size_t)bytes;
+    pl->cfg.R = R; pl->cfg.maxn = maxn; pl->cfg.maxm = maxm; pl->cfg.full_band = 0;
+    pl->cfg.row_cap = (int)(bytes / 2);
+    pl->lds = (size_t)bytes;
+    pl->nb1 = bv ? bv_nb_for(bv_first_w(max_dst_max)) : 0;
+    pl->nb2 = bv ? bv_nb_for(max_dst_max) : 0;
     return PBA_OK;
 }
 
@@ -711,19 +763,40 @@ int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pb
             PBA_FAIL(PBA_E_INVALID, "pair outside its sequence (or longer than the engine limit)");
         if (R > 0.0 && R < 1.0) mdmax = std::max(mdmax, max_dst_of(p.a_len, p.b_len, R));
     }
-    AlignCfg cfg;
-    size_t lds;
-    int st = make_cfg(ctx, R, maxn, maxm, kernel, mdmax, &cfg, &lds);
+    Plan pl;
+    int st = make_plan(ctx, R, maxn, maxm, kernel, mdmax, &pl);
     if (st != PBA_OK) return st;
-    DevBuf d_pairs, d_out;
+    DevBuf d_pairs, d_out, d_ids;
     HIPCHK(hipMalloc(&d_pairs.p, sizeof(pba_pair) * n));
     HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
     HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_align_pairs, dim3((uint32_t)n), dim3(PBA_WAVE), lds, ctx->stream, A->dev(), B->dev(),
-                       d_pairs.as<pba_pair>(), (uint32_t)n, cfg, d_out.as<pba_result>());
+#define K_PAIRS(NBV)                                                                                               \
+    hipLaunchKernelGGL(k_align_pairs<NBV>, dim3(cnt), dim3(PBA_WAVE), pl.lds, ctx->stream, A->dev(), B->dev(),     \
+                       d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>())
+    {
+        const uint32_t cnt = (uint32_t)n;
+        const uint32_t *ids = nullptr;
+        PBA_DISPATCH_NB(pl.nb1, K_PAIRS);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    // pairs whose narrow pass could not certify the goal row go round again at the reference band
+    std::vector<uint32_t> redo;
+    for (size_t q = 0; q < n; ++q)
+        if (out[q].rc == PBA_RC_UNCERTIFIED) redo.push_back((uint32_t)q);
+    if (!redo.empty()) {
+        HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * redo.size()));
+        HIPCHK(hipMemcpyAsync(d_ids.p, redo.data(), sizeof(uint32_t) * redo.size(), hipMemcpyHostToDevice, ctx->stream));
+        pl.cfg.full_band = 1;
+        const uint32_t cnt = (uint32_t)redo.size();
+        const uint32_t *ids = d_ids.as<uint32_t>();
+        PBA_DISPATCH_NB(pl.nb2, K_PAIRS);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+#undef K_PAIRS
     return PBA_OK;
 }
 
@@ -732,9 +805,8 @@ int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b
     if (!ctx || !out || la < 0 || lb < 0 || (!a && la) || (!b && lb)) return PBA_E_INVALID;
     if (la > kMaxSeqLen || lb > kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "pba_align_text");
     HIPCHK(hipSetDevice(ctx->device));
-    AlignCfg cfg;
-    size_t lds;
-    int st = make_cfg(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, max_dst_of(la, lb, R), &cfg, &lds);
+    Plan pl;
+    int st = make_plan(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, max_dst_of(la, lb, R), &pl);
     if (st != PBA_OK) return st;
     // element k of a backward accessor is p[-k]: ship [p-(len-1), p] and point at its last byte
     const size_t oa = 0, ob = ((size_t)la + 31) & ~(size_t)15;
@@ -745,8 +817,8 @@ int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b
     if (lb) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + ob, b_fwd ? b : b - (lb - 1), lb, hipMemcpyHostToDevice, ctx->stream));
     const uint8_t *da = buf.as<uint8_t>() + oa + (a_fwd || !la ? 0 : la - 1);
     const uint8_t *db = buf.as<uint8_t>() + ob + (b_fwd || !lb ? 0 : lb - 1);
-    hipLaunchKernelGGL(k_align_bytes, dim3(1), dim3(PBA_WAVE), lds, ctx->stream, da, a_fwd ? 1 : -1, la, db,
-                       b_fwd ? 1 : -1, lb, cfg, d_out.as<pba_result>());
+    hipLaunchKernelGGL(k_align_bytes, dim3(1), dim3(PBA_WAVE), pl.lds, ctx->stream, da, a_fwd ? 1 : -1, la, db,
+                       b_fwd ? 1 : -1, lb, pl.cfg, d_out.as<pba_result>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -765,22 +837,41 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = reads->n;
-    AlignCfg cfg;
-    size_t lds;
-    int st = make_cfg(ctx, R, maxn, maxm, kernel, 1 + (int)(reads->max_len * R), &cfg, &lds);
+    Plan pl;
+    int st = make_plan(ctx, R, maxn, maxm, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (st != PBA_OK) return st;
-    DevBuf d_rows, d_stats;
+    DevBuf d_rows, d_aux, d_ids;
     HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_loc_row) * (n + 1)));
-    HIPCHK(hipMalloc(&d_stats.p, 16));
-    HIPCHK(hipMemsetAsync(d_stats.p, 0, 16, ctx->stream));
-    if (n)
-        hipLaunchKernelGGL(k_locate, dim3(n), dim3(PBA_WAVE), lds, ctx->stream, ix->dev(), target->dev(), target_seq,
-                           reads->dev(), n, trials, min_len, cfg, d_rows.as<pba_loc_row>(), d_stats.as<long long>());
-    HIPCHK(hipGetLastError());
-    long long h_stats[2] = {0, 0};
-    if (n) HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_loc_row) * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h_stats, d_stats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMalloc(&d_aux.p, sizeof(LocAux) * (n + 1)));
+    std::vector<LocAux> aux(n + 1);
+#define K_LOC(NBV)                                                                                                   \
+    hipLaunchKernelGGL(k_locate<NBV>, dim3(cnt), dim3(PBA_WAVE), pl.lds, ctx->stream, ix->dev(), target->dev(),      \
+                       target_seq, reads->dev(), ids, cnt, trials, min_len, pl.cfg, d_rows.as<pba_loc_row>(),        \
+                       d_aux.as<LocAux>())
+    if (n) {
+        const uint32_t cnt = n;
+        const uint32_t *ids = nullptr;
+        PBA_DISPATCH_NB(pl.nb1, K_LOC);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(aux.data(), d_aux.p, sizeof(LocAux) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> redo;
+        for (uint32_t r = 0; r < n; ++r)
+            if (aux[r].redo) redo.push_back(r);
+        if (!redo.empty()) {      // reads with an uncertified pair: walk them again at the reference band
+            HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * redo.size()));
+            HIPCHK(hipMemcpyAsync(d_ids.p, redo.data(), sizeof(uint32_t) * redo.size(), hipMemcpyHostToDevice, ctx->stream));
+            pl.cfg.full_band = 1;
+            const uint32_t cnt = (uint32_t)redo.size();
+            const uint32_t *ids = d_ids.as<uint32_t>();
+            PBA_DISPATCH_NB(pl.nb2, K_LOC);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(aux.data(), d_aux.p, sizeof(LocAux) * n, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_loc_row) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+#undef K_LOC
     pba_loc_stats s = {0, 0, 0, 0, 0};
     int nseq = 0;
     for (uint32_t r = 0; r < n; ++r) {
@@ -789,9 +880,9 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
         if (rows[r].nseq >= 0) ++s.n_reads_kept;
         s.n_pairs += rows[r].n_pairs;
         s.n_located += rows[r].found;
+        s.n_probe_hits += aux[r].probe_hits;
+        s.n_cells += aux[r].cells;
     }
-    s.n_probe_hits = h_stats[0];
-    s.n_cells = h_stats[1];
     if (stats) *stats = s;
     return PBA_OK;
 }
@@ -805,19 +896,41 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
         PBA_FAIL(PBA_E_TOOLONG, "sequence longer than the engine limit");
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = reads->n;
-    AlignCfg cfg;
-    size_t lds;
+    Plan pl;
     // a = reference window, b = read window: the shorter side bounds max_dst (seq_aligner.h:94-102)
-    int st = make_cfg(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &cfg, &lds);
+    int st = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (st != PBA_OK) return st;
-    DevBuf d_rows;
+    DevBuf d_rows, d_redo, d_ids;
     HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_ss_row) * (n + 1)));
-    if (n)
-        hipLaunchKernelGGL(k_spaced_round, dim3(n), dim3(PBA_WAVE), lds, ctx->stream, ix->dev(), ref->dev(), ref_seq,
-                           reads->dev(), n, max_trial, overlap_min, buggy_seed_at, cfg, d_rows.as<pba_ss_row>());
-    HIPCHK(hipGetLastError());
-    if (n) HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMalloc(&d_redo.p, sizeof(int) * (n + 1)));
+#define K_SS(NBV)                                                                                                    \
+    hipLaunchKernelGGL(k_spaced_round<NBV>, dim3(cnt), dim3(PBA_WAVE), pl.lds, ctx->stream, ix->dev(), ref->dev(),   \
+                       ref_seq, reads->dev(), ids, cnt, max_trial, overlap_min, buggy_seed_at, pl.cfg,               \
+                       d_rows.as<pba_ss_row>(), d_redo.as<int>())
+    if (n) {
+        std::vector<int> h_redo(n);
+        const uint32_t cnt = n;
+        const uint32_t *ids = nullptr;
+        PBA_DISPATCH_NB(pl.nb1, K_SS);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_redo.data(), d_redo.p, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> redo;
+        for (uint32_t r = 0; r < n; ++r)
+            if (h_redo[r]) redo.push_back(r);
+        if (!redo.empty()) {
+            HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * redo.size()));
+            HIPCHK(hipMemcpyAsync(d_ids.p, redo.data(), sizeof(uint32_t) * redo.size(), hipMemcpyHostToDevice, ctx->stream));
+            pl.cfg.full_band = 1;
+            const uint32_t cnt = (uint32_t)redo.size();
+            const uint32_t *ids = d_ids.as<uint32_t>();
+            PBA_DISPATCH_NB(pl.nb2, K_SS);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+#undef K_SS
     return PBA_OK;
 }
 
