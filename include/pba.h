@@ -87,6 +87,18 @@ const char *pba_ctx_error(const pba_ctx *ctx);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own */
 int pba_ctx_set_stream(pba_ctx *ctx, void *hip_stream);
 int pba_ctx_sync(pba_ctx *ctx);
+/* HIP-event timings (on the ctx's stream) of the most recent pba_index_build / pba_locate /
+ * pba_align_batch / pba_spaced_round on this ctx: measurement support for bench.py */
+typedef struct {
+    float index_ms;        /* pba_index_build: first kernel to last kernel */
+    float align_ms;        /* first launch of the aligning kernel (all pairs / reads) */
+    float align_redo_ms;   /* second launch (pairs / reads the narrow band could not certify); 0 if none */
+    uint32_t nb_first;     /* blocks per lane of the bit-vector array in the first launch; 0 = row sweep */
+    uint32_t nb_redo;
+    uint32_t n_first;      /* pairs or reads in the first launch */
+    uint32_t n_redo;       /* pairs or reads re-run at the reference band */
+} pba_profile;
+int pba_ctx_last_profile(const pba_ctx *ctx, pba_profile *out);
 /* device facts for the bench report */
 int pba_ctx_device_info(const pba_ctx *ctx, char *name, size_t name_cap, int *n_cu, int *clock_mhz,
                         uint64_t *hbm_bytes);
@@ -132,6 +144,16 @@ typedef enum {
  * (ref_seq.h:300,307; locator.cpp:64); per-key hit order = the reference's insertion order */
 int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode,
                     pba_index **out);
+/* Multi-GPU form of the build (one process per GPU; the exchange itself is the caller's RCCL
+ * all-gather on device buffers): rank `part` of `nparts` scans its contiguous slice of the
+ * reference's visiting order and writes the raw entries (key << 32 | ordinal, any order) to the
+ * DEVICE buffer d_entries (cap u64 slots) ... */
+int pba_index_scan(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode, uint32_t part,
+                   uint32_t nparts, void *d_entries, uint64_t cap, uint64_t *n_out);
+/* ... and every rank builds the same index from the gathered DEVICE list (n slots; slots holding
+ * all-ones are padding).  seq_len / mode / mask must be those of the scan. */
+int pba_index_from_entries(pba_ctx *ctx, const void *d_entries, uint64_t n, uint32_t mask, int mode,
+                           uint32_t seq_len, pba_index **out);
 void pba_index_destroy(pba_index *ix);
 uint64_t pba_index_entries(const pba_index *ix);
 /* what get_seedmap returns (ref_seq.h:310): positions visited, not entries kept */

@@ -32,6 +32,11 @@ class PbaLocStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_reads_kept", "n_probe_hits", "n_pairs", "n_located", "n_cells")]
 
 
+class PbaProfile(C.Structure):
+    _fields_ = [("index_ms", C.c_float), ("align_ms", C.c_float), ("align_redo_ms", C.c_float),
+                ("nb_first", C.c_uint32), ("nb_redo", C.c_uint32), ("n_first", C.c_uint32), ("n_redo", C.c_uint32)]
+
+
 class PbaSsRow(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("read", "found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b", "n_trials", "n_pairs")]
@@ -57,6 +62,7 @@ SYMBOLS = {
     "pba_ctx_error": (C.c_char_p, [_P]),
     "pba_ctx_set_stream": (C.c_int, [_P, _P]),
     "pba_ctx_sync": (C.c_int, [_P]),
+    "pba_ctx_last_profile": (C.c_int, [_P, _P]),
     "pba_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_uint64)]),
     "pba_seqs_from_text": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
@@ -69,6 +75,9 @@ SYMBOLS = {
     "pba_seqs_lengths": (C.c_int, [_P, _P, C.c_uint32]),
     "pba_seqs_get_text": (C.c_int, [_P, _P, C.c_uint32, C.c_char_p, C.c_size_t]),
     "pba_index_build": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "pba_index_scan": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, _P, C.c_uint64,
+                                 C.POINTER(C.c_uint64)]),
+    "pba_index_from_entries": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(_P)]),
     "pba_index_destroy": (None, [_P]),
     "pba_index_entries": (C.c_uint64, [_P]),
     "pba_index_visited": (C.c_uint32, [_P]),

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -24,6 +25,8 @@ struct pba_ctx {
     int device;
     hipStream_t own_stream, stream;
     hipDeviceProp_t prop;
+    hipEvent_t ev[6];        // index begin/end, align begin/end, redo begin/end
+    pba_profile prof;
     char err[512];
 };
 
@@ -341,6 +344,9 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
         return PBA_E_HIP;
     }
     ctx->stream = ctx->own_stream;
+    for (int i = 0; i < 6; ++i)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PBA_E_HIP; }
+    memset(&ctx->prof, 0, sizeof ctx->prof);
     // kernels that take more than the default 64 KB of dynamic LDS
     const int big = 160 * 1024;
     (void)hipFuncSetAttribute((const void *)k_part_sort, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -357,6 +363,7 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->own_stream);
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
 }
 
@@ -371,6 +378,12 @@ int pba_ctx_set_stream(pba_ctx *ctx, void *hip_stream) {
 int pba_ctx_sync(pba_ctx *ctx) {
     if (!ctx) return PBA_E_INVALID;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_ctx_last_profile(const pba_ctx *ctx, pba_profile *out) {
+    if (!ctx || !out) return PBA_E_INVALID;
+    *out = ctx->prof;
     return PBA_OK;
 }
 
@@ -574,6 +587,88 @@ static int sort_partition_global(pba_ctx *ctx, uint64_t *d_part, uint32_t n) {
     return PBA_OK;
 }
 
+// the reference's visiting order as at most two position segments (+ what get_seedmap returns)
+struct VisitPlan {
+    ScanSeg segs[2];
+    int nseg;
+    uint32_t visited, nhead;
+    int32_t tail_top;
+};
+
+static VisitPlan visit_plan(uint32_t len, int mode) {
+    VisitPlan v;
+    v.nseg = 0; v.visited = 0; v.nhead = 0xFFFFFFFFu; v.tail_top = 0;
+    if (mode == PBA_INDEX_ALL) {                       // locator.cpp:62: for i in [0, len)
+        if (len) v.segs[v.nseg++] = ScanSeg{0, len, 0, 0};
+        v.visited = len;
+    } else {                                           // ref_seq.h:291-311, MAX_READ_LEN = 20000, N_SEQ_WORD = 16
+        const long long L = len, nmax = L - 16;
+        const long long nh = std::min(nmax, 20000ll);
+        const long long nt = std::min(L - 20000 - 16, 20000ll);
+        v.nhead = nh > 0 ? (uint32_t)nh : 0;
+        v.tail_top = (int32_t)(L - 16);
+        if (nh > 0) v.segs[v.nseg++] = ScanSeg{0, (uint32_t)nh, 0, 0};
+        if (nt > 0) v.segs[v.nseg++] = ScanSeg{(uint32_t)(L - 16 - nt + 1), (uint32_t)(L - 16 + 1), v.nhead, 1};
+        v.visited = (uint32_t)(nh + (nt < 0 ? 0 : nt));   // ref_seq.h:310 (a negative nhead is added as it is)
+    }
+    return v;
+}
+
+static uint32_t seg_grid(const ScanSeg &sg) {
+    const uint64_t chunks = ((uint64_t)sg.hi + 15) / 16 - sg.lo / 16;
+    return (uint32_t)((chunks + PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS - 1) / (PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS));
+}
+
+static int index_logp(uint64_t n) {
+    int logP = 0;
+    while (logP < PBA_IX_MAX_LOGP && (n >> logP) > 1024) ++logP;
+    return logP;
+}
+
+static pba_index *index_new(pba_ctx *ctx, uint32_t mask, uint32_t len, int mode, const VisitPlan &v) {
+    pba_index *ix = new (std::nothrow) pba_index();
+    if (!ix) return nullptr;
+    ix->ctx = ctx; ix->mask = mask; ix->seq_len = len; ix->visited = v.visited; ix->nhead = v.nhead;
+    ix->tail_top = v.tail_top; ix->mode = mode; ix->n_entries = 0; ix->d_ent = nullptr; ix->d_part_off = nullptr;
+    ix->logP = 0;
+    return ix;
+}
+
+// counts are in cnt (device, P+1 u32): turn them into offsets, allocate the entry array, let `scatter`
+// fill it (cnt then holds the cursors), sort every partition
+static int index_finish(pba_ctx *ctx, pba_index *ix, DevBuf &cnt, const std::function<void()> &scatter) {
+    const uint32_t P = 1u << ix->logP;
+    std::vector<uint32_t> h_cnt(P + 1, 0), h_off(P + 1, 0);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < P; ++p) { h_off[p] = (uint32_t)total; total += h_cnt[p]; }
+    if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "more than 2^32 index entries");
+    h_off[P] = (uint32_t)total;
+    ix->n_entries = total;
+    HIPCHK(hipMalloc((void **)&ix->d_ent, sizeof(uint64_t) * (total + 1)));
+    HIPCHK(hipMalloc((void **)&ix->d_part_off, sizeof(uint32_t) * (P + 1)));
+    HIPCHK(hipMemcpyAsync(ix->d_part_off, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cnt.p, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));   // cursors
+    if (total) {
+        scatter();
+        hipLaunchKernelGGL(k_part_sort, dim3(P), dim3(256), sizeof(uint64_t) * PBA_IX_LDS_SORT_CAP, ctx->stream,
+                           ix->d_ent, ix->d_part_off);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        for (uint32_t p = 0; p < P; ++p)
+            if (h_cnt[p] > PBA_IX_LDS_SORT_CAP) {
+                int st = sort_partition_global(ctx, ix->d_ent + h_off[p], h_cnt[p]);
+                if (st != PBA_OK) return st;
+            }
+    }
+    (void)hipEventRecord(ctx->ev[1], ctx->stream);
+    (void)hipEventSynchronize(ctx->ev[1]);
+    (void)hipEventElapsedTime(&ctx->prof.index_ms, ctx->ev[0], ctx->ev[1]);
+    return PBA_OK;
+}
+
 int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode, pba_index **out) {
     if (!ctx || !target || !out || seq >= target->n) return PBA_E_INVALID;
     if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
@@ -581,79 +676,94 @@ int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t len = target->h_len[seq];
     if (len > 0x7FFFFFF0u) PBA_FAIL(PBA_E_TOOLONG, "target sequence");
-
-    // the reference's visiting order, as at most two position segments
-    ScanSeg segs[2];
-    int nseg = 0;
-    uint32_t visited = 0, nhead = 0xFFFFFFFFu;
-    int32_t tail_top = 0;
-    if (mode == PBA_INDEX_ALL) {                       // locator.cpp:62: for i in [0, len)
-        if (len) segs[nseg++] = ScanSeg{0, len, 0, 0};
-        visited = len;
-    } else {                                           // ref_seq.h:291-311, MAX_READ_LEN = 20000, N_SEQ_WORD = 16
-        const long long L = len, nmax = L - 16;
-        const long long nh = std::min(nmax, 20000ll);
-        const long long nt = std::min(L - 20000 - 16, 20000ll);
-        nhead = nh > 0 ? (uint32_t)nh : 0;
-        tail_top = (int32_t)(L - 16);
-        if (nh > 0) segs[nseg++] = ScanSeg{0, (uint32_t)nh, 0, 0};
-        if (nt > 0) segs[nseg++] = ScanSeg{(uint32_t)(L - 16 - nt + 1), (uint32_t)(L - 16 + 1), nhead, 1};
-        visited = (uint32_t)((nh > 0 ? nh : 0) + (nt > 0 ? nt : 0));   // the int the reference returns, for sane inputs
-        if (nh < 0) visited = (uint32_t)(nh + (nt < 0 ? 0 : nt));      // (ref_seq.h:310 adds a negative nhead as is)
-    }
-
-    pba_index *ix = new (std::nothrow) pba_index();
+    const VisitPlan v = visit_plan(len, mode);
+    pba_index *ix = index_new(ctx, mask, len, mode, v);
     if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
-    ix->ctx = ctx; ix->mask = mask; ix->seq_len = len; ix->visited = visited; ix->nhead = nhead;
-    ix->tail_top = tail_top; ix->mode = mode; ix->n_entries = 0; ix->d_ent = nullptr; ix->d_part_off = nullptr;
     uint64_t npos = 0;
-    for (int s = 0; s < nseg; ++s) npos += segs[s].hi - segs[s].lo;
-    int logP = 0;
-    while (logP < PBA_IX_MAX_LOGP && (npos >> logP) > 1024) ++logP;
-    ix->logP = logP;
+    for (int s = 0; s < v.nseg; ++s) npos += v.segs[s].hi - v.segs[s].lo;
+    ix->logP = index_logp(npos);
+    const int logP = ix->logP;
     const uint32_t P = 1u << logP;
-
     const uint8_t *d_seq = target->d_packed + target->h_off[seq];
     DevBuf cnt;
-    std::vector<uint32_t> h_cnt(P + 1, 0), h_off(P + 1, 0);
     hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
-    if (e == hipSuccess) e = hipMalloc((void **)&ix->d_part_off, sizeof(uint32_t) * (P + 1));
     if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
     if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
-    auto seg_grid = [](const ScanSeg &sg) {
-        const uint64_t chunks = ((uint64_t)sg.hi + 15) / 16 - sg.lo / 16;
-        return (uint32_t)((chunks + PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS - 1) / (PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS));
-    };
-    for (int s = 0; s < nseg; ++s)
-        hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
-                           mask, segs[s], logP, cnt.as<uint32_t>());
-    e = hipMemcpyAsync(h_cnt.data(), cnt.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "k_seed_count", e); }
-    uint64_t total = 0;
-    for (uint32_t p = 0; p < P; ++p) { h_off[p] = (uint32_t)total; total += h_cnt[p]; }
-    h_off[P] = (uint32_t)total;
-    ix->n_entries = total;
-    e = hipMalloc((void **)&ix->d_ent, sizeof(uint64_t) * (total + 1));
-    if (e == hipSuccess) e = hipMemcpyAsync(ix->d_part_off, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(cnt.p, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream);   // cursors
-    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index entries", e); }
-    if (total) {
-        for (int s = 0; s < nseg; ++s)
-            hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq,
-                               len, mask, segs[s], logP, cnt.as<uint32_t>(), ix->d_ent);
-        hipLaunchKernelGGL(k_part_sort, dim3(P), dim3(256), sizeof(uint64_t) * PBA_IX_LDS_SORT_CAP, ctx->stream,
-                           ix->d_ent, ix->d_part_off);
-        e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "k_seed_scatter/k_part_sort", e); }
-        for (uint32_t p = 0; p < P; ++p)
-            if (h_cnt[p] > PBA_IX_LDS_SORT_CAP) {
-                int st = sort_partition_global(ctx, ix->d_ent + h_off[p], h_cnt[p]);
-                if (st != PBA_OK) { pba_index_destroy(ix); return st; }
-            }
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    for (int s = 0; s < v.nseg; ++s)
+        hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+                           mask, v.segs[s], logP, cnt.as<uint32_t>());
+    int st = index_finish(ctx, ix, cnt, [&]() {
+        for (int s = 0; s < v.nseg; ++s)
+            hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq,
+                               len, mask, v.segs[s], logP, cnt.as<uint32_t>(), ix->d_ent);
+    });
+    if (st != PBA_OK) { pba_index_destroy(ix); return st; }
+    *out = ix;
+    return PBA_OK;
+}
+
+int pba_index_scan(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode, uint32_t part,
+                   uint32_t nparts, void *d_entries, uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !target || !d_entries || !n_out || seq >= target->n || nparts == 0 || part >= nparts) return PBA_E_INVALID;
+    if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t len = target->h_len[seq];
+    const VisitPlan v = visit_plan(len, mode);
+    // this rank's contiguous slice of the ordinal space [0, visited)
+    const uint64_t nv = v.nseg ? (uint64_t)v.segs[v.nseg - 1].ord0 + (v.segs[v.nseg - 1].hi - v.segs[v.nseg - 1].lo) : 0;
+    const uint64_t o_lo = nv * part / nparts, o_hi = nv * (part + 1) / nparts;
+    DevBuf counter;
+    HIPCHK(hipMalloc(&counter.p, 8));
+    HIPCHK(hipMemsetAsync(counter.p, 0, 8, ctx->stream));
+    const uint8_t *d_seq = target->d_packed + target->h_off[seq];
+    for (int s = 0; s < v.nseg; ++s) {
+        const ScanSeg &g = v.segs[s];
+        const uint64_t g_lo = g.ord0, g_hi = (uint64_t)g.ord0 + (g.hi - g.lo);
+        const uint64_t a = std::max(o_lo, g_lo), b = std::min(o_hi, g_hi);
+        if (a >= b) continue;
+        ScanSeg c;
+        c.descending = g.descending; c.ord0 = (uint32_t)a;
+        if (!g.descending) { c.lo = g.lo + (uint32_t)(a - g_lo); c.hi = g.lo + (uint32_t)(b - g_lo); }
+        else { c.lo = g.hi - (uint32_t)(b - g_lo); c.hi = g.hi - (uint32_t)(a - g_lo); }
+        hipLaunchKernelGGL(k_seed_emit, dim3(seg_grid(c)), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len, mask, c,
+                           (uint64_t *)d_entries, (unsigned long long)cap, counter.as<unsigned long long>());
     }
+    HIPCHK(hipGetLastError());
+    unsigned long long h_n = 0;
+    HIPCHK(hipMemcpyAsync(&h_n, counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (h_n > cap) PBA_FAIL(PBA_E_INVALID, "pba_index_scan: entry buffer too small");
+    *n_out = h_n;
+    return PBA_OK;
+}
+
+int pba_index_from_entries(pba_ctx *ctx, const void *d_entries, uint64_t n, uint32_t mask, int mode, uint32_t seq_len,
+                           pba_index **out) {
+    if (!ctx || !out || (!d_entries && n)) return PBA_E_INVALID;
+    if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    const VisitPlan v = visit_plan(seq_len, mode);
+    pba_index *ix = index_new(ctx, mask, seq_len, mode, v);
+    if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
+    ix->logP = index_logp(n);
+    const int logP = ix->logP;
+    const uint32_t P = 1u << logP;
+    DevBuf cnt;
+    hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
+    if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
+    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
+    const uint32_t grid = (uint32_t)((n + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS);
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    if (grid)
+        hipLaunchKernelGGL(k_ent_count, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, (const uint64_t *)d_entries, n,
+                           logP, cnt.as<uint32_t>());
+    int st = index_finish(ctx, ix, cnt, [&]() {
+        hipLaunchKernelGGL(k_ent_scatter, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, (const uint64_t *)d_entries,
+                           n, logP, cnt.as<uint32_t>(), ix->d_ent);
+    });
+    if (st != PBA_OK) { pba_index_destroy(ix); return st; }
     *out = ix;
     return PBA_OK;
 }
@@ -742,6 +852,11 @@ static int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int
     return PBA_OK;
 }
 
+static void prof_finish(pba_ctx *ctx) {      // all launches of the call have completed (stream synchronised)
+    (void)hipEventElapsedTime(&ctx->prof.align_ms, ctx->ev[2], ctx->ev[3]);
+    if (ctx->prof.n_redo) (void)hipEventElapsedTime(&ctx->prof.align_redo_ms, ctx->ev[4], ctx->ev[5]);
+}
+
 static bool pair_ok(const pba_seqs *S, uint32_t seq, int pos, int len, bool backward) {
     if (seq >= S->n || len < 0 || len > kMaxSeqLen || pos < 0) return false;
     const long long L = S->h_len[seq];
@@ -776,7 +891,11 @@ int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pb
     {
         const uint32_t cnt = (uint32_t)n;
         const uint32_t *ids = nullptr;
+        (void)hipEventRecord(ctx->ev[2], ctx->stream);
         PBA_DISPATCH_NB(pl.nb1, K_PAIRS);
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        ctx->prof.nb_first = (uint32_t)pl.nb1; ctx->prof.n_first = cnt; ctx->prof.nb_redo = 0; ctx->prof.n_redo = 0;
+        ctx->prof.align_redo_ms = 0.f;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -791,12 +910,16 @@ int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pb
         pl.cfg.full_band = 1;
         const uint32_t cnt = (uint32_t)redo.size();
         const uint32_t *ids = d_ids.as<uint32_t>();
+        (void)hipEventRecord(ctx->ev[4], ctx->stream);
         PBA_DISPATCH_NB(pl.nb2, K_PAIRS);
+        (void)hipEventRecord(ctx->ev[5], ctx->stream);
+        ctx->prof.nb_redo = (uint32_t)pl.nb2; ctx->prof.n_redo = cnt;
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
 #undef K_PAIRS
+    prof_finish(ctx);
     return PBA_OK;
 }
 
@@ -851,7 +974,11 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     if (n) {
         const uint32_t cnt = n;
         const uint32_t *ids = nullptr;
+        (void)hipEventRecord(ctx->ev[2], ctx->stream);
         PBA_DISPATCH_NB(pl.nb1, K_LOC);
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        ctx->prof.nb_first = (uint32_t)pl.nb1; ctx->prof.n_first = cnt; ctx->prof.nb_redo = 0; ctx->prof.n_redo = 0;
+        ctx->prof.align_redo_ms = 0.f;
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(aux.data(), d_aux.p, sizeof(LocAux) * n, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -864,7 +991,10 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
             pl.cfg.full_band = 1;
             const uint32_t cnt = (uint32_t)redo.size();
             const uint32_t *ids = d_ids.as<uint32_t>();
+            (void)hipEventRecord(ctx->ev[4], ctx->stream);
             PBA_DISPATCH_NB(pl.nb2, K_LOC);
+            (void)hipEventRecord(ctx->ev[5], ctx->stream);
+            ctx->prof.nb_redo = (uint32_t)pl.nb2; ctx->prof.n_redo = cnt;
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(aux.data(), d_aux.p, sizeof(LocAux) * n, hipMemcpyDeviceToHost, ctx->stream));
         }
@@ -872,6 +1002,7 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
 #undef K_LOC
+    if (n) prof_finish(ctx);
     pba_loc_stats s = {0, 0, 0, 0, 0};
     int nseq = 0;
     for (uint32_t r = 0; r < n; ++r) {
@@ -911,7 +1042,11 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
         std::vector<int> h_redo(n);
         const uint32_t cnt = n;
         const uint32_t *ids = nullptr;
+        (void)hipEventRecord(ctx->ev[2], ctx->stream);
         PBA_DISPATCH_NB(pl.nb1, K_SS);
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        ctx->prof.nb_first = (uint32_t)pl.nb1; ctx->prof.n_first = cnt; ctx->prof.nb_redo = 0; ctx->prof.n_redo = 0;
+        ctx->prof.align_redo_ms = 0.f;
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_redo.data(), d_redo.p, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -924,13 +1059,17 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
             pl.cfg.full_band = 1;
             const uint32_t cnt = (uint32_t)redo.size();
             const uint32_t *ids = d_ids.as<uint32_t>();
+            (void)hipEventRecord(ctx->ev[4], ctx->stream);
             PBA_DISPATCH_NB(pl.nb2, K_SS);
+            (void)hipEventRecord(ctx->ev[5], ctx->stream);
+            ctx->prof.nb_redo = (uint32_t)pl.nb2; ctx->prof.n_redo = cnt;
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
 #undef K_SS
+    if (n) prof_finish(ctx);
     return PBA_OK;
 }
 

@@ -151,6 +151,102 @@ k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int 
     }
 }
 
+// ---- multi-GPU exchange form: a rank scans its slice of the visiting order into a flat entry list ...
+__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_seed_emit(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, uint64_t *out, unsigned long long cap,
+            unsigned long long *counter) {
+    __shared__ uint32_t wg_count, wg_base_lo, wg_base_hi;
+    if (threadIdx.x == 0) wg_count = 0;
+    __syncthreads();
+    const uint32_t chunk0 = sg.lo >> 4;
+    uint64_t be[PBA_IX_TILE_ITERS];
+    uint32_t mine = 0;
+    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+        be[it] = 0;
+        if ((uint64_t)chunk * 16 >= sg.hi) continue;
+        be[it] = chunk_bits(seq, chunk);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = chunk * 16 + k;
+            if (pos < sg.lo || pos >= sg.hi) continue;
+            if (chunk_key(be[it], k, pos, len, mask)) ++mine;
+        }
+    }
+    uint32_t slot = mine ? atomicAdd(&wg_count, mine) : 0u;      // LDS-staged reservation: one global atomic per workgroup
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long b = wg_count ? atomicAdd(counter, (unsigned long long)wg_count) : 0ull;
+        wg_base_lo = (uint32_t)b; wg_base_hi = (uint32_t)(b >> 32);
+    }
+    __syncthreads();
+    unsigned long long o = ((unsigned long long)wg_base_hi << 32 | wg_base_lo) + slot;
+    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+        if ((uint64_t)chunk * 16 >= sg.hi) continue;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = chunk * 16 + k;
+            if (pos < sg.lo || pos >= sg.hi) continue;
+            const uint32_t key = chunk_key(be[it], k, pos, len, mask);
+            if (!key) continue;
+            const uint32_t ord = sg.ord0 + (sg.descending ? sg.hi - 1 - pos : pos - sg.lo);
+            if (o < cap) out[o] = (uint64_t)key << 32 | ord;
+            ++o;
+        }
+    }
+}
+
+// ... and every rank builds the partitions from the gathered list (all-ones entries are padding)
+__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_ent_count(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cnt) {
+    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
+    const uint32_t P = 1u << logP;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PBA_IX_TILE_POS;
+    for (uint32_t i = threadIdx.x; i < PBA_IX_TILE_POS; i += blockDim.x) {
+        const uint64_t q = base + i;
+        if (q >= n) break;
+        const uint64_t e = in[q];
+        if (e != ~0ull) atomicAdd(&hist[ix_part((uint32_t)(e >> 32), logP)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
+        if (hist[p]) atomicAdd(&part_cnt[p], hist[p]);
+}
+
+__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_ent_scatter(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cursor, uint64_t *ent) {
+    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
+    __shared__ uint32_t base[1 << PBA_IX_MAX_LOGP];
+    const uint32_t P = 1u << logP;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    const uint64_t b0 = (uint64_t)blockIdx.x * PBA_IX_TILE_POS;
+    for (uint32_t i = threadIdx.x; i < PBA_IX_TILE_POS; i += blockDim.x) {
+        const uint64_t q = b0 + i;
+        if (q >= n) break;
+        const uint64_t e = in[q];
+        if (e != ~0ull) atomicAdd(&hist[ix_part((uint32_t)(e >> 32), logP)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+        const uint32_t c = hist[p];
+        base[p] = c ? atomicAdd(&part_cursor[p], c) : 0u;
+        hist[p] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < PBA_IX_TILE_POS; i += blockDim.x) {
+        const uint64_t q = b0 + i;
+        if (q >= n) break;
+        const uint64_t e = in[q];
+        if (e == ~0ull) continue;
+        const uint32_t p = ix_part((uint32_t)(e >> 32), logP);
+        ent[base[p] + atomicAdd(&hist[p], 1u)] = e;
+    }
+}
+
 // pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
 __global__ void __launch_bounds__(256) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
     extern __shared__ __align__(16) uint64_t s_ent[];

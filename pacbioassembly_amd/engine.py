@@ -145,6 +145,11 @@ class Context:
     def sync(self):
         self.check(self.lib.pba_ctx_sync(self.h), "sync")
 
+    def last_profile(self) -> dict:
+        pr = _lib.PbaProfile()
+        self.check(self.lib.pba_ctx_last_profile(self.h, C.byref(pr)), "last_profile")
+        return {n: getattr(pr, n) for n, _ in _lib.PbaProfile._fields_}
+
     def device_info(self):
         name = C.create_string_buffer(256)
         ncu, mhz, hbm = C.c_int(), C.c_int(), C.c_uint64()
@@ -181,6 +186,20 @@ class Context:
     def index_build(self, target: "SeqSet", seq: int, mask: int, mode: int = PBA_INDEX_ALL) -> "SeedIndex":
         h = C.c_void_p()
         self.check(self.lib.pba_index_build(self.h, target.h, seq, mask, mode, C.byref(h)), "index_build")
+        return SeedIndex(self, h)
+
+    def index_scan(self, target: "SeqSet", seq: int, mask: int, mode: int, part: int, nparts: int,
+                   d_entries_ptr: int, cap: int) -> int:
+        """Rank `part`'s slice of the index entries into a device buffer; returns how many were written."""
+        n = C.c_uint64()
+        self.check(self.lib.pba_index_scan(self.h, target.h, seq, mask, mode, part, nparts, C.c_void_p(d_entries_ptr),
+                                           cap, C.byref(n)), "index_scan")
+        return int(n.value)
+
+    def index_from_entries(self, d_entries_ptr: int, n: int, mask: int, mode: int, seq_len: int) -> "SeedIndex":
+        h = C.c_void_p()
+        self.check(self.lib.pba_index_from_entries(self.h, C.c_void_p(d_entries_ptr), n, mask, mode, seq_len,
+                                                   C.byref(h)), "index_from_entries")
         return SeedIndex(self, h)
 
     # -- alignment

@@ -227,3 +227,95 @@ def test_spaced_round_golden(ctx, name, kernel):
             assert (rows[col][sel] == want[sel, ci]).all(), (name, col)
         else:
             assert (rows[col] == want[:, ci]).all(), (name, col)
+
+
+# ----------------------------------------------------------------------------- exchange form of the index
+def test_index_scan_gather_build_equals_direct_build(ctx):
+    """pba_index_scan over k slices + concatenation (what the RCCL all-gather produces, padding
+    included) + pba_index_from_entries == pba_index_build, for both visiting orders."""
+    import torch
+    g = gold_json("index.json")
+    mask = eng.mask_from_pattern(MASK_PAT)
+    for c in [x for x in g["cases"] if x["name"] in ("all_100000", "ht_50000", "ht_20017", "all_repeat", "all_33")]:
+        text = index_inputs(c)
+        S = ctx.seqs_from_list([text])
+        mode = PBA_INDEX_ALL if c["mode"] == "all" else PBA_INDEX_HEAD_TAIL
+        for nparts in (1, 2, 3, 8):
+            cap = len(text) // nparts + 64
+            allent = torch.full((nparts * cap,), -1, dtype=torch.int64, device="cuda")
+            total = 0
+            for part in range(nparts):
+                sl = allent[part * cap:(part + 1) * cap]
+                total += ctx.index_scan(S, 0, c["mask"], mode, part, nparts, sl.data_ptr(), cap)
+            torch.cuda.synchronize()
+            assert total == c["n"], (c["name"], nparts)
+            ix = ctx.index_from_entries(allent.data_ptr(), nparts * cap, c["mask"], mode, len(text))
+            k, p = ix.dump()
+            assert index_digest(k, p) == c["sha256"], (c["name"], nparts)
+            if c["mode"] == "head_tail":
+                assert ix.visited == c["rv"]
+
+
+# ----------------------------------------------------------------------------- band certificate / re-run
+def test_bitvec_uncertified_pairs_rerun_at_reference_band(ctx, oracle):
+    """Reads at ~24 % error cost more than the first-pass half width (9/16 max_dst): the narrow pass
+    cannot certify the goal row, the pair is re-run at the reference band, and the answer is still
+    the reference's."""
+    g = eng.synth_genome(55, 40000)
+    reads, offs, starts = eng.synth_reads(56, g, 24, 2000, 0.08, 0.08, 0.08)
+    seqs = [g.tobytes()] + [reads[int(offs[r]):int(offs[r + 1])].tobytes() for r in range(24)]
+    S = ctx.seqs_from_list(seqs, strict_acgt=True)
+    pairs = [(r + 1, 0, 2000, 0, int(starts[r]), 40000 - int(starts[r]), 0) for r in range(24)]
+    out = ctx.align_batch(S, S, np.array(pairs, PAIR_DTYPE), 0.30, kernel=PBA_KERNEL_BITVEC)
+    prof = ctx.last_profile()
+    n_ok = 0
+    for pr, got in zip(pairs, out):
+        exp = oracle.align(seqs[pr[0]][:2000], seqs[0][pr[4]:], 0.30)
+        check_result(got, exp, pr)
+        n_ok += exp["rc"] >= 0 and exp["cost"] > 2000 * 0.3 * 9 / 16 + 2
+    assert n_ok >= 4 and prof["n_redo"] >= n_ok          # the re-run path was really taken
+    # same through the locate driver
+    T = ctx.seqs_from_list([g.tobytes()])
+    Rd = ctx.seqs_from_text(reads, offs)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    ix = ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
+    rows, st = ctx.locate(ix, T, 0, Rd, 0.30, 50, 500, kernel=PBA_KERNEL_BITVEC)
+    assert ctx.last_profile()["n_redo"] > 0
+    want, wst = oracle.locator(g, mask, 0.30, reads, offs, 50, 500, nthreads=4)
+    for c in ("found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs"):
+        assert (rows[c] == want[c]).all(), c
+    assert st == wst
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_fullsize_kernels_agree_and_recover_planted_loci(ctx):
+    """BASELINE config-2 shaped pairs (15 kb reads, R = 0.30, band 9003): too slow for the CPU oracle
+    beyond the golden handful, so check size-independent properties: the two independent kernels
+    (full-band row sweep vs bit-vector array) agree bit for bit, every read is located at the locus it
+    was sampled from, and cost is symmetric under swapping the two sequences."""
+    g = eng.synth_genome(2, 600000)
+    n = 40
+    reads, offs, starts = eng.synth_reads(3, g, n, 15000)
+    T = ctx.seqs_from_text(g, np.array([0, g.size], np.uint64), strict_acgt=True)
+    Rd = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    ix = ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
+    r_bv, s_bv = ctx.locate(ix, T, 0, Rd, 0.30, 50, 500, kernel=PBA_KERNEL_BITVEC)
+    r_rs, s_rs = ctx.locate(ix, T, 0, Rd, 0.30, 50, 500, kernel=PBA_KERNEL_ROWSWEEP)
+    assert s_bv == s_rs
+    for c in r_bv.dtype.names:
+        assert (r_bv[c] == r_rs[c]).all(), c
+    f = r_bv["found"] == 1
+    assert f.sum() >= n * 0.7
+    # located position == sampled start + probe offset, up to the indels inside the first j bases
+    assert (np.abs(r_bv["pos"][f] - (starts[f].astype(np.int64) + r_bv["j"][f])) <= 12).all()
+    assert (r_bv["cost"][f] < 0.3 * 15000).all() and (r_bv["matlen_b"][f] >= r_bv["seglen"][f] * 0.7).all()
+    # transposition symmetry on explicit pairs: align(a,b).cost == align(b,a).cost, matlens swap
+    pairs = [(0, int(p), 15000 - int(j) + 4501, r, int(j), 15000 - int(j), 0)
+             for r, (p, j) in enumerate(zip(r_bv["pos"], r_bv["j"])) if f[r]][:12]
+    fwd = ctx.align_batch(T, Rd, np.array(pairs, PAIR_DTYPE), 0.30, kernel=PBA_KERNEL_BITVEC)
+    rev = ctx.align_batch(Rd, T, np.array([(p[3], p[4], p[5], p[0], p[1], p[2], 0) for p in pairs], PAIR_DTYPE), 0.30,
+                          kernel=PBA_KERNEL_BITVEC)
+    for x, y in zip(fwd, rev):
+        assert int(x["cost"]) == int(y["cost"]) and int(x["matlen_a"]) == int(y["matlen_b"]) \
+            and int(x["matlen_b"]) == int(y["matlen_a"]) and int(x["rc"]) == int(x["matlen_b"])
