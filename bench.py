@@ -50,6 +50,19 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """CPU cores this process may really use: the affinity mask capped by the cgroup CPU quota (a 1-GPU box
+    exposes every host core in the mask but grants a 16-core share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("PBA_MAX_HOST_THREADS", "64")))
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -72,7 +85,7 @@ def main():
     ctx = Context(local_rank)
     kernel = {"auto": eng.PBA_KERNEL_AUTO, "rowsweep": eng.PBA_KERNEL_ROWSWEEP, "bitvec": eng.PBA_KERNEL_BITVEC}[a.kernel]
     mask = eng.mask_from_pattern("111*11*11*1*1111")
-    nthreads = a.cpu_threads or len(os.sched_getaffinity(0))
+    nthreads = a.cpu_threads or host_cores()
 
     # ---- synthetic inputs: genome seed 2, reads seed 3 (+ rank), 5/5/5 % ins/del/sub
     t0 = time.time()
@@ -88,17 +101,13 @@ def main():
 
     def exchange_index():
         """N > 1: scan 1/N of the genome's positions, all-gather the entries over RCCL, build the lookup."""
-        cap = (a.genome + world - 1) // world + 64
+        from pacbioassembly_amd import distributed as pd
+        cap = pd.slice_capacity(a.genome, world)
         mine = torch.empty(cap, dtype=torch.int64, device="cuda")
         n_mine = ctx.index_scan(T, 0, mask, PBA_INDEX_ALL, rank, world, mine.data_ptr(), cap)
-        counts = torch.zeros(world, dtype=torch.int64, device="cuda")
-        counts[rank] = n_mine
-        dist.all_reduce(counts)
-        mine[n_mine:] = -1                                        # all-ones entries sort last and are dropped
-        allent = torch.empty(cap * world, dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(allent, mine)
+        allent, _ = pd.all_gather_entries(mine, n_mine)
         torch.cuda.synchronize()
-        return ctx.index_from_entries(allent.data_ptr(), cap * world, mask, PBA_INDEX_ALL, a.genome)
+        return ctx.index_from_entries(allent.data_ptr(), allent.numel(), mask, PBA_INDEX_ALL, a.genome)
 
     def step():
         ix = exchange_index() if world > 1 else ctx.index_build(T, 0, mask, PBA_INDEX_ALL)

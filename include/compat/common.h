@@ -1,0 +1,50 @@
+// common.h -- source-compatible stand-in for /root/reference/src/common.h (limits, typedefs, LOG) for
+// programs that are re-targeted at the MI355X engine.  Own code; see INTEGRATION.md.
+#ifndef PBA_COMPAT_COMMON_H
+#define PBA_COMPAT_COMMON_H
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <list>
+#include <unordered_map>
+
+#include "pba.h"
+
+#ifndef PBA_COMPAT_QUIET
+#define LOG(...) fprintf(stderr, __VA_ARGS__)          // common.h:22-28 (DBG is defined there)
+#else
+#define LOG(...)
+#endif
+
+#define MAX_SEQ_LEN 800000      // common.h:31
+#define MAX_READ_LEN 20000      // common.h:33
+#define MAX_DIFF_LEN 6000       // common.h:35
+#define MAXR 0.3                // common.h:37
+#ifndef OVERLAP_MIN
+#define OVERLAP_MIN 64          // common.h:39; overridable (the reference's ref_test fixtures need <= 43)
+#endif
+
+typedef unsigned t_seed;                                            // common.h:44
+typedef unsigned char t_bseq;                                       // common.h:49
+// common.h:54 uses __gnu_cxx::hash_map; the hot path only uses find/end/size/clear/operator[] and the
+// per-key list order, which std::unordered_map provides identically
+typedef std::unordered_map<unsigned, std::list<int> > hash_table;
+typedef hash_table::iterator sm_it;                                 // common.h:59
+
+// One engine context per process, created on first use (the reference keeps global singletons too:
+// spaced_seed.cpp:71-96).  No GPU -> the program stops; there is no CPU fallback.
+inline pba_ctx *pba_compat_ctx() {
+    static pba_ctx *ctx = NULL;
+    if (!ctx) {
+        const char *dev = getenv("PBA_DEVICE");
+        int st = pba_ctx_create(dev ? atoi(dev) : 0, &ctx);
+        if (st != PBA_OK) {
+            fprintf(stderr, "pba: cannot create a device context: %s\n", pba_strerror(st));
+            exit(1);
+        }
+    }
+    return ctx;
+}
+
+#endif

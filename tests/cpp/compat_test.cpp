@@ -1,0 +1,131 @@
+// compat_test.cpp -- the reference's own unit-test expectations (test/dna_test.cpp, test/aligner_test.cpp,
+// test/ref_test.cpp "basic"), restated against include/compat/*.h, i.e. running on the MI355X through libpba.so.
+// Own code: only the known-answer values are the reference's.  Exit code 0 = all passed.
+#define OVERLAP_MIN 16
+#define PBA_COMPAT_QUIET
+#include <fstream>
+#include <string>
+
+#include "dna_seq.h"
+#include "ref_seq.h"
+#include "seq_aligner.h"
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                                   \
+    do {                                                                              \
+        ++g_checks;                                                                   \
+        if (!(cond)) { ++g_fail; fprintf(stderr, "FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); } \
+    } while (0)
+
+static void dna_binary() {             // test/dna_test.cpp:18-29
+    char dna_str[] = "ACGTGTCATCGGATCAACCGGTT";
+    unsigned char bin_buf[64] = {0};
+    char txt_buf[41];
+    CHECK(10 == dna_seq::text2bin(dna_str, bin_buf, 14));
+    CHECK(23 == dna_seq::bin2text(bin_buf, txt_buf, 41));
+    CHECK(std::string(dna_str) == txt_buf);
+    CHECK(0x34DAB41B == dna_seq::seed_at(bin_buf, 0));
+    CHECK(0xD068D36E == dna_seq::seed_at(bin_buf, 1));
+    CHECK(0x41A34DBB == dna_seq::seed_at(bin_buf, 2));
+    CHECK(0xAF058D36 == dna_seq::seed_at(bin_buf, 7));
+}
+
+static void accessor() {               // test/dna_test.cpp:32-60
+    char dna_str[] = "ACGTGTCATCGGATCAACCGGTT";
+    seq_accessor da(dna_str, true, 4);
+    CHECK(4 == da.length());
+    CHECK('A' == da.next()); CHECK('C' == da.next()); CHECK('G' == da.next()); CHECK('T' == da.next());
+    CHECK('G' == da.at(2)); CHECK(!da.has_more());
+    da.reset(2);
+    CHECK(da.has_more()); CHECK('G' == da.next()); CHECK('T' == da.next()); CHECK(!da.has_more());
+    seq_accessor db(dna_str + 4, false, 3);
+    CHECK(3 == db.length());
+    CHECK('G' == db.next()); CHECK('T' == db.next()); CHECK(db.has_more()); CHECK('G' == db.next());
+    CHECK(!db.has_more()); CHECK('T' == db.at(1));
+    db.reset(1);
+    CHECK('T' == db.next()); CHECK('G' == db.next()); CHECK(!db.has_more());
+}
+
+static void aligner(const char *real_align_path) {   // test/aligner_test.cpp:44-117 (score expectations)
+    char dna_ref[] = "ACGTAACCGGTT", dna_seg1[] = "CGTAAGC", dna_seg2[] = "GTAACGGGTTAA", dna_seg3[] = "TCGTAAC";
+    t_aligner *pal = new t_aligner();
+    {
+        seq_accessor ref1(dna_ref, true, 7), seg1(dna_seg1, true, 6);
+        int rc = pal->align(&seg1, &ref1);
+        CHECK(6 <= rc && rc <= 7); CHECK(2 == pal->final_cost());
+        seq_accessor ref2(dna_ref, true, 8), seg2(dna_seg1, true, 7);
+        CHECK(7 == pal->align(&seg2, &ref2)); CHECK(2 == pal->final_cost());
+        seq_accessor ref3(dna_ref, true, 8), seg3(dna_seg3, true, 7);
+        CHECK(7 == pal->align(&seg3, &ref3)); CHECK(1 == pal->final_cost());
+    }
+    {   // backward
+        seq_accessor ref(dna_ref + 7, false, 7), seg(dna_seg1 + 6, false, 7);
+        CHECK(7 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost());
+    }
+    {   // overlay
+        seq_accessor ref(dna_ref + 2, true, 10), seg(dna_seg2, true, 12);
+        CHECK(10 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost());
+    }
+    {   // remove (nedit / edits[] belong to the traceback row, not checked here)
+        seq_accessor ref(dna_ref, true, 10), seg(dna_ref + 1, true, 9);
+        CHECK(10 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost());
+        ref.reset(0); seg.reset(0);
+        CHECK(9 == pal->align(&ref, &seg)); CHECK(1 == pal->final_cost());
+    }
+    {   // sample: real reads
+        std::ifstream fin(real_align_path);
+        std::string ref_str, seg_str;
+        fin >> ref_str >> seg_str;
+        CHECK(ref_str.size() == 736);
+        seq_accessor ref((char *)ref_str.c_str() + ref_str.length() - 1, false, ref_str.length());
+        seq_accessor seg((char *)seg_str.c_str() + seg_str.length() - 1, false, seg_str.length());
+        CHECK(0 < pal->align(&seg, &ref));
+        CHECK(736 == pal->matlen_a && 736 == pal->matlen_b && 7 == pal->final_cost());
+        fin >> ref_str >> seg_str;
+        seq_accessor ref2((char *)ref_str.c_str(), true, ref_str.length());
+        seq_accessor seg2((char *)seg_str.c_str(), true, seg_str.length());
+        CHECK(-1 == pal->align(&seg2, &ref2));
+    }
+    {   // size guard, seq_aligner.h:104-107
+        seq_aligner<100, 30> small(0.3);
+        std::string a(120, 'A');
+        seq_accessor x((char *)a.c_str(), true, 120), y((char *)a.c_str(), true, 120);
+        CHECK(-1 == small.align(&x, &y));
+    }
+    delete pal;
+}
+
+static void ref_basic() {              // test/ref_test.cpp:100-128
+    char dna_txt[] = "ACGTAACCGGTTAAACCCGGGTTTTGCAAAAAAAAAAAAAAAA";
+    const int sz = (int)strlen(dna_txt);
+    unsigned char bseg[24];
+    dna_seq::text2bin(dna_txt, bseg, 24);
+    ref_seq *pref = new ref_seq(bseg);
+    CHECK((unsigned)sz == pref->length());
+    CHECK(!pref->contained(-1)); CHECK(pref->contained(0)); CHECK(pref->contained(sz - 1)); CHECK(!pref->contained(sz));
+    seq_accessor f = pref->get_accessor(0, true);
+    for (int i = 0; i < sz; ++i) CHECK(dna_txt[i] == f.next());
+    seq_accessor b = pref->get_accessor(sz - 1, false);
+    for (int i = sz - 1; i >= 0; --i) CHECK(dna_txt[i] == b.next());
+    hash_table seedmap;
+    pref->get_seedmap(seedmap, 0xFFFFFFFF);
+    CHECK((size_t)(sz - 15 - 1) == seedmap.size());
+    for (int i = 0; i < sz - 16; ++i) CHECK(seedmap.find(dna_seq::encode(dna_txt + i)) != seedmap.end());
+    CHECK(seedmap.find(dna_seq::encode(dna_txt + sz - 15)) == seedmap.end());
+    // locked try_align against the reference text itself (ref_seq.h:259-265)
+    t_aligner al;
+    char seg[] = "ACGTAACCGGTTAAACCCGGGTTTTGC";
+    seq_accessor ac(seg, true, 27);
+    CHECK(pref->try_align(&al, 0, &ac));
+    CHECK(al.matlen_a >= OVERLAP_MIN && al.final_cost() == 0);
+    delete pref;
+}
+
+int main(int argc, char **argv) {
+    dna_binary();
+    accessor();
+    aligner(argc > 1 ? argv[1] : "tests/golden/real_align.txt");
+    ref_basic();
+    printf("%d checks, %d failed\n", g_checks, g_fail);
+    return g_fail ? 1 : 0;
+}

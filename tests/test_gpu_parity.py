@@ -319,3 +319,22 @@ def test_fullsize_kernels_agree_and_recover_planted_loci(ctx):
     for x, y in zip(fwd, rev):
         assert int(x["cost"]) == int(y["cost"]) and int(x["matlen_a"]) == int(y["matlen_b"]) \
             and int(x["matlen_b"]) == int(y["matlen_a"]) and int(x["rc"]) == int(x["matlen_b"])
+
+
+# ----------------------------------------------------------------------------- the reference's API surface
+def test_compat_headers_cpp(lib):
+    """include/compat/{dna_seq,seq_aligner,ref_seq}.h: the reference's own test expectations (dna_test,
+    aligner_test scores, ref_test basic) compiled with g++ against the compat headers and run on the GPU."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    out = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "compat_test")
+    libdir = os.path.join(ROOT, "pacbioassembly_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+                    os.path.join(ROOT, "include", "compat"), "-o", exe, os.path.join(ROOT, "tests", "cpp", "compat_test.cpp"),
+                    "-L", libdir, "-lpba", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([exe, os.path.join(GOLD, "real_align.txt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failed" in r.stdout
