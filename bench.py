@@ -190,6 +190,7 @@ def main():
         orc = Oracle()
         ns = min(a.cpu_sample, a.reads)
         coffs = np.arange(ns + 1, dtype=np.uint64) * np.uint64(a.read_len)
+        orc.prefault(nthreads, a.read_len, a.R)      # DP matrices mapped and touched before the clock starts
         t0 = time.perf_counter()
         crow, cst = orc.locator(genome, mask, a.R, cpu_reads[: ns * a.read_len], coffs, a.trials, 500,
                                 nthreads=nthreads)
@@ -200,6 +201,7 @@ def main():
                "sample": f"first {ns} reads of the same workload (index build + locate), {ct:.1f} s wall, "
                          f"{cst['n_pairs']} pairs, {cst['n_located']} located, {cst['n_cells'] / ct / 1e9:.2f} GCUPS",
                "gpu_rows_identical_on_sample": bool(same)}
+        orc.release()
 
     out = {
         "metric": METRIC, "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,

