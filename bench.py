@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--R", type=float, default=0.30)
     ap.add_argument("--trials", type=int, default=50)
     ap.add_argument("--kernel", choices=["auto", "rowsweep", "bitvec"], default="auto")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
     return ap.parse_args()
 

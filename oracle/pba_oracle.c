@@ -356,11 +356,24 @@ struct orc_seedmap {
     orc_knode **b;
 };
 
+/* __gnu_cxx::hash_map rounds the bucket hint up to a prime (its identity hash is then reduced modulo that
+ * prime, which spreads masked keys whose low bits are mostly zero); same here. */
+static size_t next_prime(size_t n)
+{
+    if (n < 17) n = 17;
+    for (n |= 1;; n += 2) {
+        int ok = 1;
+        for (size_t d = 3; d * d <= n; d += 2)
+            if (n % d == 0) { ok = 0; break; }
+        if (ok) return n;
+    }
+}
+
 orc_seedmap *orc_seedmap_new(size_t nb)
 {
     orc_seedmap *sm = (orc_seedmap *)calloc(1, sizeof *sm);
     if (!sm) return NULL;
-    if (nb < 16) nb = 16;
+    nb = next_prime(nb);
     sm->nb = nb;
     sm->b = (orc_knode **)calloc(nb, sizeof *sm->b);
     if (!sm->b) { free(sm); return NULL; }

@@ -76,13 +76,63 @@ __device__ __forceinline__ uint32_t wave_ror1(uint32_t v) {
 #endif
 }
 
+// 64 bits of an accessor's 2-bit stream starting at base index `idx` (may be unaligned / slightly out of
+// range, see BaseStream): bit 63:62 = base idx, ..., bit 1:0 = base idx+31
+__device__ __forceinline__ uint64_t load_bases32(const uint8_t *seq, int idx) {
+    const uint8_t *p = seq + (idx >> 2);
+    const uint64_t hi = __builtin_bswap64(ld_u64(p)), nx = __builtin_bswap64(ld_u64(p + 8));
+    const int sh = 2 * (idx & 3);
+    return sh ? (hi << sh) | (nx >> (64 - sh)) : hi;
+}
+
+// bit q of the result = bit 2q of x (q = 0..31)
+__device__ __forceinline__ uint32_t compress_even64(uint64_t x) {
+    uint32_t lo = (uint32_t)x & 0x55555555u, hi = (uint32_t)(x >> 32) & 0x55555555u;
+    lo = (lo | (lo >> 1)) & 0x33333333u; hi = (hi | (hi >> 1)) & 0x33333333u;
+    lo = (lo | (lo >> 2)) & 0x0F0F0F0Fu; hi = (hi | (hi >> 2)) & 0x0F0F0F0Fu;
+    lo = (lo | (lo >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 4)) & 0x00FF00FFu;
+    lo = (lo | (lo >> 8)) & 0x0000FFFFu; hi = (hi | (hi >> 8)) & 0x0000FFFFu;
+    return lo | (hi << 16);
+}
+
+// bit planes of 32 consecutive accessor elements starting at element e: bit r of plo/phi = low/high bit of
+// element e+r
+__device__ __forceinline__ void load_planes32(const PackedFetch &f, int e, uint32_t &plo, uint32_t &phi) {
+    if (f.dir > 0) {
+        const uint64_t x = load_bases32(f.seq, f.org + e);            // element r at bits 63-2r : 62-2r
+        plo = __builtin_bitreverse32(compress_even64(x));
+        phi = __builtin_bitreverse32(compress_even64(x >> 1));
+    } else {
+        const uint64_t x = load_bases32(f.seq, f.org - e - 31);       // element r (base org-e-r) at bits 2r+1 : 2r
+        plo = compress_even64(x);
+        phi = compress_even64(x >> 1);
+    }
+}
+
+// d = a + b + carry-in, carry-out to a lane mask: v_addc_co_u32 with SGPR-pair carries.  One instruction does
+// "shift left by one, OR in the delta entering at the top row, hand out the delta leaving at the bottom row".
+__device__ __forceinline__ uint32_t addc_mask(uint32_t a, uint32_t b, uint64_t cin, uint64_t &cout) {
+    uint32_t d;
+    asm("v_addc_co_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cout) : "v"(a), "v"(b), "s"(cin));
+    return d;
+}
+
 // One sweep with half-width w.  Returns 0 when all diagonal checks pass (then best / bestj hold the
 // goal-row minimum and its column), else the first failing row.
+//
+// Instruction budget (measured on MI355X, tools/ubench_ops: and/or/xor/add/sub/not/bitop3/ashr issue every
+// ~2.5 cycles per SIMD, shifts, bfe, alignbit, lshl_or, add3, addc and DPP moves every ~4.3): a Myers block is
+// 9 full-rate ops + 3 v_addc_co (the carries are the horizontal deltas entering / leaving the block, kept as lane
+// masks in SGPR pairs), and the lane-to-lane hand-off of those deltas is a SCALAR rotate of the two masks -- no
+// DPP, no VALU.  The diagonal's D0 bits are collected with one bitop3 per block and a rotating one-hot; text
+// elements come from two 32-step bit-plane registers.  Everything rare sits behind one compare (t == t_next).
 template <int NB>
-__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int w, double R,
-                           int &best_out, int &bestj_out) {
+__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int w,
+                                           double R, int &best_out, int &bestj_out) {
     constexpr int RB = 32 * NB;                 // rows per superblock
     const int lane = threadIdx.x & (PBA_WAVE - 1);
+    m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);   // wave-uniform by construction
+    w = __builtin_amdgcn_readfirstlane(w);
     const int S = (m + RB - 1) / RB;            // superblocks
     const int s_m = S - 1;                      // superblock, block and bit of row m
     const int nb_m = ((m - 1) - s_m * RB) >> 5, r_m = (m - 1) & 31;
@@ -90,112 +140,189 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     const int t1 = m + s_m;                     // step at which cell (m,m) is produced
     const int t_end = hi_last + s_m;
 
-    uint32_t Pv[NB], Mv[NB], Plo[NB], Phi[NB];
-    int s_cur = lane, lo, hi, base_row;
+    uint32_t Pv[NB], Mv[NB], Plo[NB], Phi[NB], acc[NB];
+    int s_cur = lane;
+    int t_evt;         // next step at which this lane's window opens or (after that) has just closed
+    int t_close1 = 0;  // first step after the window
+    int t_hin_end;     // last step at which the lane above still delivers hout for this lane's column
+    int t_diag0;       // step at which this lane's first row is on the diagonal
+    int t_dstart;      // = t_diag0 until the diagonal has entered this lane's rows
+    int t_seg;         // step at which the current 32-row diagonal segment of this lane is complete
+    bool opened = false;
 
-    auto open_superblock = [&]() {
-        base_row = s_cur * RB;
+    auto open_superblock = [&]() {              // s_cur names the superblock this lane now owns
+        const int base_row = s_cur * RB;
+        opened = false;
         if (s_cur < S) {
-            lo = max(1, base_row + 1 - w);
-            hi = min(n, base_row + RB + w);
-            // bit planes of the pattern rows: bit r of Plo/Phi = low/high bit of row base_row+32*nb+r+1
-            BaseStream rs;
+            const int lo = max(1, base_row + 1 - w), hi = min(n, base_row + RB + w);
+            t_evt = lo + s_cur;
+            t_close1 = hi + s_cur + 1;
+            t_hin_end = s_cur > 0 ? base_row + w + s_cur : INT_MIN;
+            t_diag0 = t_dstart = base_row + 1 + s_cur;
+            t_seg = min(t_diag0 + 31, m + s_cur);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                uint32_t pl = 0, ph = 0;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    rs.seek(rowsF, base_row + 32 * nb + 16 * half);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t c = (uint32_t)rs.next(rowsF.dir);
-                        pl |= (c & 1u) << (16 * half + r);
-                        ph |= (c >> 1) << (16 * half + r);
-                    }
-                }
-                Plo[nb] = pl; Phi[nb] = ph;
-            }
-        } else {
-            lo = INT_MAX; hi = INT_MAX;          // nothing left for this lane
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) { Plo[nb] = 0; Phi[nb] = 0; }
+            for (int nb = 0; nb < NB; ++nb) load_planes32(rowsF, base_row + 32 * nb, Plo[nb], Phi[nb]);
+        } else {                                // nothing left for this lane
+            t_evt = INT_MAX; t_close1 = INT_MAX; t_hin_end = INT_MIN; t_diag0 = INT_MAX - RB; t_dstart = INT_MAX;
+            t_seg = INT_MAX - 1;
         }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; }
     };
     open_superblock();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; acc[nb] = 0u; }
 
-    BaseStream tx;
+    uint32_t wl = 0, wh = 0;                     // text bit planes: bit k = low / high bit of the element of step tb+k
     int score = 0, best = INT_MAX, bestj = 0, fail_row = 0;
-    uint32_t msg = 1u << 0 | 0u;                 // {score << 2 | hout + 1}
+    uint32_t dmw = 0;                            // one-hot: bit of the diagonal cell in its block's word (0: not in this lane)
+    uint64_t hp_last = ~0ull, hn_last = 0ull;    // lane masks: delta +1 / -1 leaving each lane's last block in the previous step
+    int t_next = min(min(t_evt, t_seg + 1), t_dstart);   // the one rare-event compare of the step loop
 
-    for (int t = 1; t <= t_end; ++t) {
-        int j = t - s_cur;
-        if (j > hi) {                            // window finished: take this lane's next superblock
-            s_cur += PBA_WAVE;
-            open_superblock();
-            j = t - s_cur;
-            tx.seek(colsF, j - 1);
-        }
-        if (j == lo) {                           // window opens: column lo-1 is "+1 per row"
+    // text planes for the 32 steps starting at the wave-uniform step tb (element of step t is t - s_cur - 1)
+    auto load_text = [&](int tb) { load_planes32(colsF, tb - s_cur - 1, wl, wh); };
+
+    // A 32-row diagonal segment ended at step t-1 (row i = t-1-s_cur, or row m): check its rows against
+    // seq_aligner.h:185 and carry the diagonal score on.
+    // `above`: the score register of the lane above, fetched by the caller with all lanes enabled
+    auto segment_done = [&](int t, int above) {
+        const int rr = t - 1 - t_diag0, i = t - 1 - s_cur, cnt = (rr & 31) + 1, i0 = i - cnt, q = rr >> 5;
+        if (q == 0) score = s_cur == 0 ? 0 : above;      // D(i0,i0): the lane above finished its rows >= 2 steps ago
+        uint32_t dw = 0;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; }
-        }
-        if ((t & 15) == 1) tx.seek(colsF, j - 1);          // wave-uniform refill of the text window
-        const int c = tx.next(colsF.dir);
-        const uint32_t clo = 0u - (uint32_t)(c & 1), chi = 0u - (uint32_t)(c >> 1);
-
-        // what the superblock above produced for this same column one step ago
-        const uint32_t m_in = wave_ror1(msg);
-        int hin = 1;                             // row above the window: "+1 per column"
-        if (s_cur > 0 && j <= base_row + w) hin = (int)(m_in & 3u) - 1;
-
-        const int rr = j - base_row - 1;         // row of the diagonal cell inside this superblock
-        uint32_t d0_sel = 0, ph_m = 0, mh_m = 0;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            uint32_t Eq = ~(Plo[nb] ^ clo) & ~(Phi[nb] ^ chi);
-            const uint32_t pv = Pv[nb], mv = Mv[nb];
-            const uint32_t hneg = hin < 0 ? 1u : 0u, hpos = hin > 0 ? 1u : 0u;
-            const uint32_t Xv = Eq | mv;
-            Eq |= hneg;
-            const uint32_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-            uint32_t Ph = mv | ~(Xh | pv);
-            uint32_t Mh = pv & Xh;
-            if ((rr >> 5) == nb) d0_sel = Xh | mv;          // D0: bit r set iff D(i,j) == D(i-1,j-1)
-            if (nb == nb_m) { ph_m = Ph; mh_m = Mh; }
-            hin = (int)(Ph >> 31) - (int)(Mh >> 31);         // hout of this block = hin of the next
-            Ph = (Ph << 1) | hpos;
-            Mh = (Mh << 1) | hneg;
-            Pv[nb] = Mh | ~(Xv | Ph);
-            Mv[nb] = Ph & Xv;
-        }
-
-        if (t <= t1) {
-            // diagonal cell (j,j): D(j,j) = D(j-1,j-1) + 1 - D0 bit; early failure seq_aligner.h:185
-            if ((unsigned)rr < (unsigned)RB && j <= m) {
-                if (rr == 0) score = s_cur == 0 ? 0 : (int)(m_in >> 2);
-                score += 1 - (int)((d0_sel >> (rr & 31)) & 1u);
-                if (j > 10 && (double)score > (double)j * R && fail_row == 0) fail_row = j;
-                if (j == m) { best = score; bestj = m; }
+        for (int nb = 0; nb < NB; ++nb) dw = q == nb ? acc[nb] : dw;
+        dw &= 0xFFFFFFFFu >> (32 - cnt);
+        // D(i0+k, i0+k) = score + k - popcount(low k bits of dw); non-decreasing in k
+        const int end = score + cnt - __builtin_popcount(dw);
+        const int ifirst = max(i0 + 1, 11);                                   // rows <= 10 are never checked
+        if (i >= ifirst && (double)end > (double)ifirst * R && fail_row == 0) {
+            for (int k = ifirst - i0; k <= cnt; ++k) {                        // row by row
+                const int d = score + k - __builtin_popcount(dw & (0xFFFFFFFFu >> (32 - k)));
+                if ((double)d > (double)(i0 + k) * R) { fail_row = i0 + k; break; }
             }
-            if (__builtin_amdgcn_ballot_w64(fail_row != 0)) break;
-        } else if (s_cur == s_m && j > m && j <= hi) {
-            // goal row m right of the diagonal: D(m,j) = D(m,j-1) + horizontal delta (seq_aligner.h:202-211)
-            score += (int)((ph_m >> r_m) & 1u) - (int)((mh_m >> r_m) & 1u);
-            if (score < best) { best = score; bestj = j; }
         }
-        msg = ((uint32_t)score << 2) | (uint32_t)(hin + 1);
+        score = end;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = 0;     // the next block's word starts clean
+        if (i == m) { best = score; bestj = m; }
+        if (i == m || rr == RB - 1) { t_seg = INT_MAX - 1; dmw = 0; }         // the diagonal leaves this lane's rows
+        else t_seg = min(t_seg + 32, m + s_cur);
+    };
+
+    // rare, divergent: segment finished last step / window opens now / window closed last step / diagonal enters
+#define PBA_BV_RARE()                                                                 \
+    if (__builtin_amdgcn_ballot_w64(t == t_next)) {      /* wave-uniform: all lanes enabled for the shuffle */ \
+      const int above = __shfl(score, (lane + PBA_WAVE - 1) & (PBA_WAVE - 1), PBA_WAVE); \
+      if (t == t_next) {                                                              \
+        if (t == t_seg + 1) segment_done(t, above);                                   \
+        if (t == t_evt) {                                                             \
+            if (opened) { s_cur += PBA_WAVE; open_superblock(); }                     \
+            if (t == t_evt) {                                                         \
+                _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; } \
+                opened = true;                                                        \
+                t_evt = t_close1;                                                     \
+            }                                                                         \
+            load_text(t - ((t - 1) & 31));                                            \
+        }                                                                             \
+        if (t == t_dstart) {                                                          \
+            dmw = 1u; t_dstart = INT_MAX;                                             \
+            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] = 0;            \
+        }                                                                             \
+        t_next = min(min(t_evt, t_seg + 1), t_dstart);                                \
+      }                                                                               \
     }
 
-    // rows fail in increasing order of step, so the smallest recorded row is the first failing row
-    int fr = fail_row ? fail_row : INT_MAX;
+    // hin of each lane's first block: the lane above's hout of the previous step, rotated one lane up, where that
+    // lane was still inside its window; elsewhere the row above the window counts "+1 per column"
+#define PBA_BV_HIN()                                                                  \
+    const uint64_t valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);               \
+    uint64_t hp = (((hp_last << 1) | (hp_last >> 63)) & valid) | ~valid;              \
+    uint64_t hn = ((hn_last << 1) | (hn_last >> 63)) & valid;
+
+    // one block update (hp / hn: lane masks of the delta entering at the block's top row, replaced by the one leaving)
+#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, D0)                                         \
+    {                                                                                \
+        const uint32_t Eq = ~(Plo[nb] ^ clo) & ~(Phi[nb] ^ chi);                     \
+        const uint32_t pv = Pv[nb], mv = Mv[nb];                                     \
+        const uint32_t Xv = Eq | mv;                                                 \
+        uint64_t unused;                                                             \
+        const uint32_t sum = addc_mask(Eq & pv, pv, hn, unused);   /* hn as carry-in == Eq |= 1 at the top row */ \
+        const uint32_t Xh = (sum ^ pv) | Eq;                                         \
+        const uint32_t Ph = mv | ~(Xh | pv);                                         \
+        const uint32_t Mh = pv & Xh;                                                 \
+        D0 = Xh | mv;               /* bit r set iff D(i,j) == D(i-1,j-1) */         \
+        PH_PRE = Ph; MH_PRE = Mh;                                                    \
+        const uint32_t Ph2 = addc_mask(Ph, Ph, hp, hp);                              \
+        const uint32_t Mh2 = addc_mask(Mh, Mh, hn, hn);                              \
+        Pv[nb] = Mh2 | ~(Xv | Ph2);                                                  \
+        Mv[nb] = Ph2 & Xv;                                                           \
+    }
+
+    // ------------------------------------------------------------------ phase 1: down to cell (m,m)
+    int t = 1;
+    bool failed = false;
+    for (; t <= t1; ++t) {
+        PBA_BV_RARE();
+        const int k = (__builtin_amdgcn_readfirstlane(t) - 1) & 31;
+        if (k == 0) {                            // wave-uniform, every 32 steps: next text planes, poll for failure
+            load_text(t);
+            if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; break; }
+        }
+        const uint32_t clo = (uint32_t)((int32_t)(wl << (31 - k)) >> 31), chi = (uint32_t)((int32_t)(wh << (31 - k)) >> 31);
+        PBA_BV_HIN();
 #pragma unroll
-    for (int d = 1; d < PBA_WAVE; d <<= 1) fr = min(fr, __shfl_xor(fr, d, PBA_WAVE));
-    if (fr != INT_MAX) return fr;
-    const int owner = s_m & (PBA_WAVE - 1);
-    best_out = __shfl(best, owner, PBA_WAVE);
-    bestj_out = __shfl(bestj, owner, PBA_WAVE);
+        for (int nb = 0; nb < NB; ++nb) {
+            uint32_t d0, php, mhp;
+            PBA_BV_BLOCK(nb, php, mhp, d0);
+            (void)php; (void)mhp;
+            acc[nb] |= d0 & dmw;                 // D0 bit of the diagonal cell; garbage while the diagonal is elsewhere
+        }
+        hp_last = hp; hn_last = hn;
+        dmw = (dmw << 1) | (dmw >> 31);
+    }
+    if (!failed) {                               // segments that ended in the last step (the one holding row m does)
+        const int above = __shfl(score, (lane + PBA_WAVE - 1) & (PBA_WAVE - 1), PBA_WAVE);
+        if (t == t_seg + 1) segment_done(t, above);
+        failed = __builtin_amdgcn_ballot_w64(fail_row != 0) != 0;
+    }
+    if (failed) {
+        int fr = fail_row ? fail_row : INT_MAX;  // rows fail in increasing order of step: the smallest is the first
+#pragma unroll
+        for (int d = 1; d < PBA_WAVE; d <<= 1) fr = min(fr, __shfl_xor(fr, d, PBA_WAVE));
+        return __builtin_amdgcn_readfirstlane(fr);
+    }
+    t_seg = INT_MAX - 1; t_dstart = INT_MAX;
+    t_next = t_evt;
+
+    // ------------------------------------------------------------------ phase 2: goal row right of the diagonal
+    const bool owner = s_cur == s_m;             // the lane holding row m
+    for (; t <= t_end; ++t) {
+        PBA_BV_RARE();
+        const int k = (__builtin_amdgcn_readfirstlane(t) - 1) & 31;
+        if (k == 0) load_text(t);
+        const uint32_t clo = (uint32_t)((int32_t)(wl << (31 - k)) >> 31), chi = (uint32_t)((int32_t)(wh << (31 - k)) >> 31);
+        PBA_BV_HIN();
+        uint32_t ph_m = 0, mh_m = 0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            uint32_t d0, php, mhp;
+            PBA_BV_BLOCK(nb, php, mhp, d0);
+            (void)d0;
+            if (nb == nb_m) { ph_m = php; mh_m = mhp; }
+        }
+        hp_last = hp; hn_last = hn;
+        if (owner) {                             // D(m,j) = D(m,j-1) + horizontal delta at row m (seq_aligner.h:202-211)
+            score += (int)((ph_m >> r_m) & 1u) - (int)((mh_m >> r_m) & 1u);
+            if (score < best) { best = score; bestj = t - s_m; }
+        }
+    }
+#undef PBA_BV_BLOCK
+#undef PBA_BV_HIN
+#undef PBA_BV_RARE
+    // v_readlane: the results are wave-uniform and the compiler must know it, or every loop that depends on
+    // them (the callers' candidate walks, and through their lengths this function's own step loop) is treated
+    // as divergent and its counters and bounds move from SGPRs into VGPRs
+    const int own_lane = s_m & (PBA_WAVE - 1);
+    best_out = __builtin_amdgcn_readlane(best, own_lane);
+    bestj_out = __builtin_amdgcn_readlane(bestj, own_lane);
     return 0;
 }
 

@@ -65,18 +65,18 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
             int y = wave_prefix_min(v - lane, lane);
             y = min(y, carry + 1);
             const int nv = y + lane;
-            carry = __shfl(nv, PBA_WAVE - 1, PBA_WAVE);
+            carry = __builtin_amdgcn_readlane(nv, PBA_WAVE - 1);
             __builtin_amdgcn_wave_barrier();
             if (inb) row[c] = (uint16_t)min(nv, 0xFFFF);
         }
         __builtin_amdgcn_wave_barrier();
         // early failure on the diagonal cell, seq_aligner.h:185 (skipped when (i,i) is not a cell, A.4)
         if (i > 10 && i <= len_b) {
-            const int d = row[m];
+            const int d = __builtin_amdgcn_readfirstlane((int)row[m]);
             if ((double)d > (double)i * R) { o.fail_row = i; return; }
         }
         if (len_a > len_b && i >= len_b) {              // goal_cell, seq_aligner.h:192-201
-            const int v = row[len_b - i + m];
+            const int v = __builtin_amdgcn_readfirstlane((int)row[len_b - i + m]);
             if (i == len_b || v < col_best) { col_best = v; col_ml = i; }
         }
     }
@@ -95,7 +95,7 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
             const int ov = __shfl_xor(bv, d, PBA_WAVE), oj = __shfl_xor(bj, d, PBA_WAVE);
             if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
         }
-        o.matlen_a = len_a; o.matlen_b = bj; o.cost = bv;
+        o.matlen_a = len_a; o.matlen_b = __builtin_amdgcn_readfirstlane(bj); o.cost = __builtin_amdgcn_readfirstlane(bv);
     }
     // acceptance, seq_aligner.h:114
     o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;

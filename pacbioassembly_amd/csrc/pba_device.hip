@@ -125,6 +125,15 @@ struct AlignCfg {
     int full_band;   // bit-vector kernel: 0 = narrow first pass (may answer PBA_RC_UNCERTIFIED), 1 = reference band
 };
 
+// Wavefronts per workgroup: the CU admits only 16 workgroups, so single-wave workgroups cap the bit-vector
+// kernel at 4 waves/SIMD; four independent waves per workgroup (one pair / read each, no barrier, own LDS
+// slice) lift that.  The row sweep keeps one wave per workgroup because its band row can take most of the LDS.
+template <int NB> struct Wpb {
+    static constexpr int v = NB ? 4 : 1;
+    // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+    static constexpr int occ = NB == 0 ? 1 : (NB <= 2 ? 6 : (NB <= 4 ? 5 : 3));
+};
+
 template <int NB>
 __device__ __forceinline__ void align_dispatch(const PackedFetch &fa, int la, const PackedFetch &fb, int lb,
                                                const AlignCfg &cfg, void *lds, AlnOut &o) {
@@ -147,12 +156,15 @@ __device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
 
 // ids (nullable): the subset of pairs / reads to process (second, full-band launch)
 template <int NB>
-__global__ void __launch_bounds__(PBA_WAVE)
+__global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg,
               pba_result *out) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    if (blockIdx.x >= n) return;
-    const uint32_t q = ids ? ids[blockIdx.x] : blockIdx.x;
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
+    const uint32_t slot = blockIdx.x * Wpb<NB>::v + wave;
+    if (slot >= n) return;
+    uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    const uint32_t q = ids ? ids[slot] : slot;
     const pba_pair pr = pairs[q];
     PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
     PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
@@ -188,12 +200,15 @@ struct LocAux {
 
 // locator.cpp:70-92
 template <int NB>
-__global__ void __launch_bounds__(PBA_WAVE)
+__global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *ids, uint32_t n, int trials,
          int min_len, AlignCfg cfg, pba_loc_row *rows, LocAux *aux) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    if (blockIdx.x >= n) return;
-    const uint32_t r = ids ? ids[blockIdx.x] : blockIdx.x;
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
+    const uint32_t slot = blockIdx.x * Wpb<NB>::v + wave;
+    if (slot >= n) return;
+    uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    const uint32_t r = ids ? ids[slot] : slot;
     const int len = (int)Rd.len[r];
     int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0, redo = 0;
     long long ncell = 0;
@@ -276,12 +291,15 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, i
 }
 
 template <int NB>
-__global__ void __launch_bounds__(PBA_WAVE)
+__global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const uint32_t *ids, uint32_t n,
                int max_trial, int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows, int *redo) {
-    extern __shared__ __align__(16) uint8_t lds[];
-    if (blockIdx.x >= n) return;
-    const uint32_t r = ids ? ids[blockIdx.x] : blockIdx.x;
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
+    const uint32_t slot = blockIdx.x * Wpb<NB>::v + wave;
+    if (slot >= n) return;
+    uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    const uint32_t r = ids ? ids[slot] : slot;
     const uint8_t *ref = Rf.packed + Rf.off[rseq_id];
     const int ref_len = (int)Rf.len[rseq_id];
     const uint8_t *rseq = Rd.packed + Rd.off[r];
@@ -886,7 +904,8 @@ int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pb
     HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
     HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
 #define K_PAIRS(NBV)                                                                                               \
-    hipLaunchKernelGGL(k_align_pairs<NBV>, dim3(cnt), dim3(PBA_WAVE), pl.lds, ctx->stream, A->dev(), B->dev(),     \
+    hipLaunchKernelGGL(k_align_pairs<NBV>, dim3((cnt + Wpb<NBV>::v - 1) / Wpb<NBV>::v), dim3(PBA_WAVE * Wpb<NBV>::v), \
+                       pl.lds * Wpb<NBV>::v, ctx->stream, A->dev(), B->dev(),                                      \
                        d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>())
     {
         const uint32_t cnt = (uint32_t)n;
@@ -968,7 +987,8 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     HIPCHK(hipMalloc(&d_aux.p, sizeof(LocAux) * (n + 1)));
     std::vector<LocAux> aux(n + 1);
 #define K_LOC(NBV)                                                                                                   \
-    hipLaunchKernelGGL(k_locate<NBV>, dim3(cnt), dim3(PBA_WAVE), pl.lds, ctx->stream, ix->dev(), target->dev(),      \
+    hipLaunchKernelGGL(k_locate<NBV>, dim3((cnt + Wpb<NBV>::v - 1) / Wpb<NBV>::v), dim3(PBA_WAVE * Wpb<NBV>::v),     \
+                       pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), target->dev(),                                  \
                        target_seq, reads->dev(), ids, cnt, trials, min_len, pl.cfg, d_rows.as<pba_loc_row>(),        \
                        d_aux.as<LocAux>())
     if (n) {
@@ -1035,7 +1055,8 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
     HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_ss_row) * (n + 1)));
     HIPCHK(hipMalloc(&d_redo.p, sizeof(int) * (n + 1)));
 #define K_SS(NBV)                                                                                                    \
-    hipLaunchKernelGGL(k_spaced_round<NBV>, dim3(cnt), dim3(PBA_WAVE), pl.lds, ctx->stream, ix->dev(), ref->dev(),   \
+    hipLaunchKernelGGL(k_spaced_round<NBV>, dim3((cnt + Wpb<NBV>::v - 1) / Wpb<NBV>::v),                             \
+                       dim3(PBA_WAVE * Wpb<NBV>::v), pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), ref->dev(),       \
                        ref_seq, reads->dev(), ids, cnt, max_trial, overlap_min, buggy_seed_at, pl.cfg,               \
                        d_rows.as<pba_ss_row>(), d_redo.as<int>())
     if (n) {

@@ -142,7 +142,7 @@ class Oracle:
     # index
     def index(self, text: bytes, mask: int, mode: str = "all"):
         """Returns (keys, pos) sorted by key with hit order inside a key, and the builder's return value."""
-        sm = self.lib.orc_seedmap_new(1 << 16)
+        sm = self.lib.orc_seedmap_new(1 << 21)
         buf = np.frombuffer(text + b"\0" * 32, np.uint8)
         if mode == "all":
             rv = self.lib.orc_index_all(sm, _ptr(buf), len(text), mask)
