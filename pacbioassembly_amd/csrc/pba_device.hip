@@ -26,6 +26,7 @@ struct pba_ctx {
     hipStream_t own_stream, stream;
     hipDeviceProp_t prop;
     hipEvent_t ev[6];        // index begin/end, align begin/end, redo begin/end
+    uint32_t *d_queue;       // work-queue counters of the persistent aligning kernels (one per launch in flight)
     pba_profile prof;
     char err[512];
 };
@@ -154,23 +155,39 @@ __device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
     }
 }
 
+// Work distribution: every aligning kernel is launched with just enough workgroups to fill the chip and each
+// wavefront pulls work items (pairs / reads) from a global counter until it runs dry.  A true 15 kb pair costs
+// ~500x a false candidate, so a fixed item-per-wavefront mapping leaves most of a workgroup idle while its
+// slowest wave finishes; the queue keeps every wavefront busy to the end.  Exit: the counter only grows, so every
+// wave eventually reads a value >= n and leaves.
+// NOTE: every lane calls atomicAdd (lane 0 adds 1, the others 0; the compiler folds that into one wave-level
+// atomic).  The obvious `if (lane == 0) v = atomicAdd(q, 1)` inside a persistent loop is miscompiled by ROCm 7.2's
+// clang (the loop's exit mask ends up covering every lane but lane 0 and the wave spins forever);
+// tools/ubench_queue.hip reproduces both forms.
+__device__ __forceinline__ uint32_t next_slot(uint32_t *queue) {
+    const uint32_t v = atomicAdd(queue, (threadIdx.x & (PBA_WAVE - 1)) == 0 ? 1u : 0u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // ids (nullable): the subset of pairs / reads to process (second, full-band launch)
 template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg,
-              pba_result *out) {
+              pba_result *out, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
-    const uint32_t slot = blockIdx.x * Wpb<NB>::v + wave;
-    if (slot >= n) return;
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
-    const uint32_t q = ids ? ids[slot] : slot;
-    const pba_pair pr = pairs[q];
-    PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
-    PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
-    AlnOut o;
-    align_dispatch<NB>(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
-    store_result(out + q, o);
+    for (;;) {                                // persistent wavefront: pull the next pair until the queue is dry
+        const uint32_t slot = next_slot(queue);
+        if (slot >= n) break;
+        const uint32_t q = ids ? ids[slot] : slot;
+        const pba_pair pr = pairs[q];
+        PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
+        PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+        AlnOut o;
+        align_dispatch<NB>(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
+        store_result(out + q, o);
+    }
 }
 
 __global__ void __launch_bounds__(PBA_WAVE)
@@ -202,12 +219,13 @@ struct LocAux {
 template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *ids, uint32_t n, int trials,
-         int min_len, AlignCfg cfg, pba_loc_row *rows, LocAux *aux) {
+         int min_len, AlignCfg cfg, pba_loc_row *rows, LocAux *aux, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
-    const uint32_t slot = blockIdx.x * Wpb<NB>::v + wave;
-    if (slot >= n) return;
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    for (;;) {                                // persistent wavefront: pull the next read until the queue is dry
+    const uint32_t slot = next_slot(queue);
+    if (slot >= n) break;
     const uint32_t r = ids ? ids[slot] : slot;
     const int len = (int)Rd.len[r];
     int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0, redo = 0;
@@ -244,6 +262,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
         row->found = found; row->j = fj; row->pos = fpos; row->cost = fcost;
         row->seglen = found ? len - fj : 0; row->matlen_a = fma; row->matlen_b = fmb; row->n_pairs = npairs;
         aux[r].cells = ncell; aux[r].probe_hits = nhit; aux[r].redo = redo;
+    }
     }
 }
 
@@ -293,12 +312,13 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, i
 template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const uint32_t *ids, uint32_t n,
-               int max_trial, int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows, int *redo) {
+               int max_trial, int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows, int *redo, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
-    const uint32_t slot = blockIdx.x * Wpb<NB>::v + wave;
-    if (slot >= n) return;
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    for (;;) {
+    const uint32_t slot = next_slot(queue);
+    if (slot >= n) break;
     const uint32_t r = ids ? ids[slot] : slot;
     const uint8_t *ref = Rf.packed + Rf.off[rseq_id];
     const int ref_len = (int)Rf.len[rseq_id];
@@ -319,6 +339,7 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const 
         row->ref_pos = st.ref_pos; row->cost = st.cost; row->matlen_a = st.ma; row->matlen_b = st.mb;
         row->n_trials = st.ntrials; row->n_pairs = st.npairs;
         redo[r] = st.redo;
+    }
     }
 }
 
@@ -365,6 +386,7 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     for (int i = 0; i < 6; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PBA_E_HIP; }
     memset(&ctx->prof, 0, sizeof ctx->prof);
+    if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
     // kernels that take more than the default 64 KB of dynamic LDS
     const int big = 160 * 1024;
     (void)hipFuncSetAttribute((const void *)k_part_sort, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -382,6 +404,7 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->own_stream);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipFree(ctx->d_queue);
     delete ctx;
 }
 
@@ -870,6 +893,17 @@ static int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int
     return PBA_OK;
 }
 
+// Workgroups for a persistent launch: enough to fill every CU (up to 8 waves per SIMD, as many as the LDS
+// allows), never more than there are work items.  Any residency works: the queue needs no co-residency.
+static uint32_t persistent_grid(const pba_ctx *ctx, uint32_t n_items, int waves_per_wg, size_t lds_per_wave) {
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    uint32_t wg_per_cu = 32u / (uint32_t)waves_per_wg;
+    const size_t lds_wg = lds_per_wave * (size_t)waves_per_wg;
+    if (lds_wg) wg_per_cu = std::min<uint32_t>(wg_per_cu, (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_wg));
+    const uint32_t need = (n_items + (uint32_t)waves_per_wg - 1) / (uint32_t)waves_per_wg;
+    return std::max(1u, std::min(need, cus * wg_per_cu));
+}
+
 static void prof_finish(pba_ctx *ctx) {      // all launches of the call have completed (stream synchronised)
     (void)hipEventElapsedTime(&ctx->prof.align_ms, ctx->ev[2], ctx->ev[3]);
     if (ctx->prof.n_redo) (void)hipEventElapsedTime(&ctx->prof.align_redo_ms, ctx->ev[4], ctx->ev[5]);
@@ -904,9 +938,10 @@ int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pb
     HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
     HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
 #define K_PAIRS(NBV)                                                                                               \
-    hipLaunchKernelGGL(k_align_pairs<NBV>, dim3((cnt + Wpb<NBV>::v - 1) / Wpb<NBV>::v), dim3(PBA_WAVE * Wpb<NBV>::v), \
-                       pl.lds * Wpb<NBV>::v, ctx->stream, A->dev(), B->dev(),                                      \
-                       d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>())
+    (void)hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream);                                                         \
+    hipLaunchKernelGGL(k_align_pairs<NBV>, dim3(persistent_grid(ctx, cnt, Wpb<NBV>::v, pl.lds)),                    \
+                       dim3(PBA_WAVE * Wpb<NBV>::v), pl.lds * Wpb<NBV>::v, ctx->stream, A->dev(), B->dev(),         \
+                       d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), ctx->d_queue)
     {
         const uint32_t cnt = (uint32_t)n;
         const uint32_t *ids = nullptr;
@@ -987,10 +1022,11 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     HIPCHK(hipMalloc(&d_aux.p, sizeof(LocAux) * (n + 1)));
     std::vector<LocAux> aux(n + 1);
 #define K_LOC(NBV)                                                                                                   \
-    hipLaunchKernelGGL(k_locate<NBV>, dim3((cnt + Wpb<NBV>::v - 1) / Wpb<NBV>::v), dim3(PBA_WAVE * Wpb<NBV>::v),     \
-                       pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), target->dev(),                                  \
+    (void)hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream);                                                           \
+    hipLaunchKernelGGL(k_locate<NBV>, dim3(persistent_grid(ctx, cnt, Wpb<NBV>::v, pl.lds)),                           \
+                       dim3(PBA_WAVE * Wpb<NBV>::v), pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), target->dev(),     \
                        target_seq, reads->dev(), ids, cnt, trials, min_len, pl.cfg, d_rows.as<pba_loc_row>(),        \
-                       d_aux.as<LocAux>())
+                       d_aux.as<LocAux>(), ctx->d_queue)
     if (n) {
         const uint32_t cnt = n;
         const uint32_t *ids = nullptr;
@@ -1055,10 +1091,11 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
     HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_ss_row) * (n + 1)));
     HIPCHK(hipMalloc(&d_redo.p, sizeof(int) * (n + 1)));
 #define K_SS(NBV)                                                                                                    \
-    hipLaunchKernelGGL(k_spaced_round<NBV>, dim3((cnt + Wpb<NBV>::v - 1) / Wpb<NBV>::v),                             \
+    (void)hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream);                                                           \
+    hipLaunchKernelGGL(k_spaced_round<NBV>, dim3(persistent_grid(ctx, cnt, Wpb<NBV>::v, pl.lds)),                     \
                        dim3(PBA_WAVE * Wpb<NBV>::v), pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), ref->dev(),       \
                        ref_seq, reads->dev(), ids, cnt, max_trial, overlap_min, buggy_seed_at, pl.cfg,               \
-                       d_rows.as<pba_ss_row>(), d_redo.as<int>())
+                       d_rows.as<pba_ss_row>(), d_redo.as<int>(), ctx->d_queue)
     if (n) {
         std::vector<int> h_redo(n);
         const uint32_t cnt = n;
