@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "rowsweep", "bitvec"], default="auto")
     ap.add_argument("--cpu-sample", type=int, default=512, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores available to this process")
+    ap.add_argument("--exchange", action="store_true",
+                    help="take the multi-GPU seed-index exchange path (scan slice -> RCCL all-gather -> build) even at N=1")
     return ap.parse_args()
 
 
@@ -79,8 +81,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to time")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.exchange
+    if use_dist:
+        os.environ["NCCL_DEBUG"] = os.environ.get("PBA_NCCL_DEBUG", "WARN")   # no RCCL banner on stdout: ONE JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     ctx = Context(local_rank)
     kernel = {"auto": eng.PBA_KERNEL_AUTO, "rowsweep": eng.PBA_KERNEL_ROWSWEEP, "bitvec": eng.PBA_KERNEL_BITVEC}[a.kernel]
@@ -110,7 +115,7 @@ def main():
         return ctx.index_from_entries(allent.data_ptr(), allent.numel(), mask, PBA_INDEX_ALL, a.genome)
 
     def step():
-        ix = exchange_index() if world > 1 else ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
+        ix = exchange_index() if use_dist else ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
         prof_ix = ctx.last_profile()["index_ms"]
         rows, st = ctx.locate(ix, T, 0, Rd, a.R, a.trials, 500, kernel=kernel)
         prof = ctx.last_profile()
@@ -121,7 +126,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -146,8 +151,7 @@ def main():
         pairs, located, cells = st["n_pairs"], st["n_located"], st["n_cells"]
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = 1e3 * elapsed / a.steps
@@ -211,7 +215,7 @@ def main():
                                "seed-hash + banded align (locator.cpp path, R=0.30, 50 probe offsets)",
                    "reads_per_gpu": a.reads, "read_len": a.read_len, "genome": a.genome, "R": a.R,
                    "trials": a.trials, "mask": "111*11*11*1*1111", "kernel": a.kernel,
-                   "parallelism": f"reads sharded over {world} GPU(s)" + (", seed index all-gathered" if world > 1 else "")},
+                   "parallelism": f"reads sharded over {world} GPU(s)" + (", seed index all-gathered over RCCL" if use_dist else "")},
         "pairs_per_step": pairs, "located_per_step": located, "successful_pairs_per_s": round(located * a.steps / elapsed, 2),
         "band_gcups": round(cells * a.steps / elapsed / 1e9, 1),
         "kernel_ms": {"index_build": round(index_ms, 3), "locate_first": round(align_ms, 3),
@@ -220,7 +224,7 @@ def main():
         "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
