@@ -117,6 +117,19 @@ __device__ __forceinline__ uint32_t addc_mask(uint32_t a, uint32_t b, uint64_t c
     return d;
 }
 
+// (a | b) & c and a | b in one full-rate v_bitop3_b32 each (the compiler would pick the half-rate v_and_or_b32)
+__device__ __forceinline__ uint32_t or_and(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // (a|b)&c: (0xF0|0xCC)&0xAA
+    return d;
+}
+// sign-extended bit k of x (k wave-uniform): 0 or ~0
+__device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
+    uint32_t d;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(d) : "v"(x), "s"(k));
+    return d;
+}
+
 // One sweep with half-width w.  Returns 0 when all diagonal checks pass (then best / bestj hold the
 // goal-row minimum and its column), else the first failing row.
 //
@@ -238,7 +251,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     uint64_t hn = ((hn_last << 1) | (hn_last >> 63)) & valid;
 
     // one block update (hp / hn: lane masks of the delta entering at the block's top row, replaced by the one leaving)
-#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, D0)                                         \
+#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, XH, MV_OLD)                                 \
     {                                                                                \
         const uint32_t Eq = ~(Plo[nb] ^ clo) & ~(Phi[nb] ^ chi);                     \
         const uint32_t pv = Pv[nb], mv = Mv[nb];                                     \
@@ -248,7 +261,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         const uint32_t Xh = (sum ^ pv) | Eq;                                         \
         const uint32_t Ph = mv | ~(Xh | pv);                                         \
         const uint32_t Mh = pv & Xh;                                                 \
-        D0 = Xh | mv;               /* bit r set iff D(i,j) == D(i-1,j-1) */         \
+        XH = Xh; MV_OLD = mv;       /* D0 = Xh | mv: bit r set iff D(i,j) == D(i-1,j-1) */ \
         PH_PRE = Ph; MH_PRE = Mh;                                                    \
         const uint32_t Ph2 = addc_mask(Ph, Ph, hp, hp);                              \
         const uint32_t Mh2 = addc_mask(Mh, Mh, hn, hn);                              \
@@ -266,14 +279,16 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             load_text(t);
             if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; break; }
         }
-        const uint32_t clo = (uint32_t)((int32_t)(wl << (31 - k)) >> 31), chi = (uint32_t)((int32_t)(wh << (31 - k)) >> 31);
+        const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            uint32_t d0, php, mhp;
-            PBA_BV_BLOCK(nb, php, mhp, d0);
+            uint32_t xh, mvo, php, mhp;
+            PBA_BV_BLOCK(nb, php, mhp, xh, mvo);
             (void)php; (void)mhp;
-            acc[nb] |= d0 & dmw;                 // D0 bit of the diagonal cell; garbage while the diagonal is elsewhere
+            // keep the diagonal cell's D0 bit (garbage while the diagonal is in another block: the word is
+            // cleared when the diagonal enters)
+            acc[nb] |= or_and(xh, mvo, dmw);
         }
         hp_last = hp; hn_last = hn;
         dmw = (dmw << 1) | (dmw >> 31);
@@ -298,14 +313,14 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         PBA_BV_RARE();
         const int k = (__builtin_amdgcn_readfirstlane(t) - 1) & 31;
         if (k == 0) load_text(t);
-        const uint32_t clo = (uint32_t)((int32_t)(wl << (31 - k)) >> 31), chi = (uint32_t)((int32_t)(wh << (31 - k)) >> 31);
+        const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
         uint32_t ph_m = 0, mh_m = 0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            uint32_t d0, php, mhp;
-            PBA_BV_BLOCK(nb, php, mhp, d0);
-            (void)d0;
+            uint32_t xh, mvo, php, mhp;
+            PBA_BV_BLOCK(nb, php, mhp, xh, mvo);
+            (void)xh; (void)mvo;
             if (nb == nb_m) { ph_m = php; mh_m = mhp; }
         }
         hp_last = hp; hn_last = hn;
