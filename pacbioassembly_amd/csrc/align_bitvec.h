@@ -17,12 +17,13 @@
 //
 // Mapping to the wavefront.  Rows (the shorter sequence, m of them) are cut into superblocks of
 // NB*32 rows; superblock s lives in lane s mod 64 and processes column j at step t = j + s, so
-// a column flows down the lanes one lane per step: the horizontal delta leaving the bottom row
-// of a superblock (hout) and the running diagonal score travel to the next lane with one DPP
-// wave-rotate per step.  Only columns within w of the superblock's rows are processed
-// (lo..hi); cells left of the window are taken as "+1 per row" and the row above the window
-// as "+1 per column", which are real (if expensive) paths, so everything computed is an upper
-// bound W >= U that equals U whenever U's optimal path stays within |i-j| <= w.
+// a column flows down the lanes one lane per step.  The horizontal deltas leaving the bottom row
+// of a superblock are carry-outs of v_addc_co_u32, i.e. lane masks in SGPR pairs, and reach the
+// next lane through a scalar 64-bit rotate of those masks (no DPP, no VALU).  Only columns within
+// w of the superblock's rows are processed (lo..hi); cells left of the window are taken as "+1
+// per row" and the row above the window as "+1 per column", which are real (if expensive) paths,
+// so everything computed is an upper bound W >= U that equals U whenever U's optimal path stays
+// within |i-j| <= w.
 // With w >= max_dst/2 every diagonal verdict is exact (an out-of-window path costs >= 2w+2 >
 // floor(i*R)); the goal row is exact when its minimum is <= w (any unseen path costs >= w+1);
 // otherwise the pair is re-run with w = max_dst, the reference's own band, where the two
@@ -48,36 +49,8 @@ __device__ __host__ inline int bv_nb_for(int w) {
     return nb <= 4 ? nb : (nb <= 6 ? 6 : (nb <= 8 ? 8 : 0));   // instantiated: 1,2,3,4,6,8; 0 = too wide
 }
 
-// sequential reader of an accessor's 2-bit elements through a 64-bit register window
-struct BaseStream {
-    uint64_t X;
-    // position on element e of accessor f (e may be slightly out of range: sequence sets carry
-    // 1 KB of readable slack on both sides and out-of-range elements are never used)
-    __device__ __forceinline__ void seek(const PackedFetch &f, int e) {
-        const int idx = f.org + f.dir * e;
-        if (f.dir > 0) X = __builtin_bswap64(ld_u64(f.seq + (idx >> 2))) << (2 * (idx & 3));
-        else X = __builtin_bswap64(ld_u64(f.seq + (idx >> 2) - 7)) >> (2 * (3 - (idx & 3)));
-    }
-    __device__ __forceinline__ int next(int dir) {     // valid for >= 16 calls after a seek
-        int c;
-        if (dir > 0) { c = (int)(X >> 62); X <<= 2; }
-        else { c = (int)(X & 3); X >>= 2; }
-        return c;
-    }
-};
-
-__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) {
-    // lane i receives lane (i-1) mod 64
-#ifdef PBA_BV_USE_BPERMUTE
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & 63) + 63) & 63) << 2), (int)v);
-#else
-    // DPP wave_ror:1 (0x13C), available on gfx9-family ISAs
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xF, 0xF, false);
-#endif
-}
-
 // 64 bits of an accessor's 2-bit stream starting at base index `idx` (may be unaligned / slightly out of
-// range, see BaseStream): bit 63:62 = base idx, ..., bit 1:0 = base idx+31
+// range: sequence sets carry 1 KB of readable slack on both sides): bit 63:62 = base idx, ..., bit 1:0 = base idx+31
 __device__ __forceinline__ uint64_t load_bases32(const uint8_t *seq, int idx) {
     const uint8_t *p = seq + (idx >> 2);
     const uint64_t hi = __builtin_bswap64(ld_u64(p)), nx = __builtin_bswap64(ld_u64(p + 8));

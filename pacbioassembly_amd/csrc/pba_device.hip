@@ -132,7 +132,7 @@ struct AlignCfg {
 template <int NB> struct Wpb {
     static constexpr int v = NB ? 4 : 1;
     // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
-    static constexpr int occ = NB == 0 ? 1 : (NB <= 2 ? 6 : (NB <= 4 ? 6 : 3));
+    static constexpr int occ = NB == 0 ? 1 : (NB <= 4 ? 6 : 3);   // measured on configs[1]: 5 -> 123 ms, 6 -> 105 ms, 8 (spills in the step loop) -> 113 ms
 };
 
 template <int NB>

@@ -338,3 +338,58 @@ def test_compat_headers_cpp(lib):
     r = subprocess.run([exe, os.path.join(GOLD, "real_align.txt")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failed" in r.stdout
+
+
+# ----------------------------------------------------------------------------- error behaviour of the boundary
+def test_error_codes_not_exceptions_across_the_abi(ctx):
+    S = ctx.seqs_from_list([b"ACGT" * 50, b"ACGTTGCA" * 20])
+    # pair outside its sequence / negative length / bad R / unknown kernel -> PBA_E_INVALID, never a crash
+    for pr in [(0, 0, 500, 1, 0, 100, 0), (0, 190, 50, 1, 0, 100, 0), (5, 0, 10, 1, 0, 10, 0), (0, 10, 50, 1, 0, 20, 1)]:
+        with pytest.raises(PbaError) as e:
+            ctx.align_batch(S, S, np.array([pr], PAIR_DTYPE), 0.3)
+        assert e.value.status == -1, pr
+    for R in (0.0, 1.0, -0.1):
+        with pytest.raises(PbaError) as e:
+            ctx.align_batch(S, S, np.array([(0, 0, 100, 1, 0, 100, 0)], PAIR_DTYPE), R)
+        assert e.value.status == -1
+    with pytest.raises(PbaError) as e:
+        ctx.align_batch(S, S, np.array([(0, 0, 100, 1, 0, 100, 0)], PAIR_DTYPE), 0.3, kernel=7)
+    assert e.value.status == -1
+    # a read longer than the engine limit -> PBA_E_TOOLONG from the drivers
+    big = ctx.seqs_from_list([b"A" * 70000])
+    T = ctx.seqs_from_list([b"ACGT" * 5000])
+    ix = ctx.index_build(T, 0, eng.mask_from_pattern(MASK_PAT), PBA_INDEX_ALL)
+    with pytest.raises(PbaError) as e:
+        ctx.locate(ix, T, 0, big, 0.3)
+    assert e.value.status == -4
+    # locate wants a PBA_INDEX_ALL index of that very sequence
+    ix2 = ctx.index_build(T, 0, eng.mask_from_pattern(MASK_PAT), PBA_INDEX_HEAD_TAIL)
+    with pytest.raises(PbaError) as e:
+        ctx.locate(ix2, T, 0, S, 0.3)
+    assert e.value.status == -1
+    # empty batches are fine
+    assert ctx.align_batch(S, S, np.zeros(0, PAIR_DTYPE), 0.3).size == 0
+    empty = ctx.seqs_from_list([])
+    rows, st = ctx.locate(ix, T, 0, empty, 0.3)
+    assert rows.size == 0 and st["n_pairs"] == 0
+
+
+def test_runs_on_a_caller_owned_stream(ctx, oracle):
+    """pba_ctx_set_stream: the engine enqueues on torch's stream (how bench.py and a torch host would use it)."""
+    import torch
+    g = eng.synth_genome(91, 20000)
+    reads, offs, _ = eng.synth_reads(92, g, 32, 900)
+    s = torch.cuda.Stream()
+    ctx.set_stream(s.cuda_stream)
+    try:
+        T = ctx.seqs_from_text(g, np.array([0, g.size], np.uint64))
+        Rd = ctx.seqs_from_text(reads, offs)
+        mask = eng.mask_from_pattern(MASK_PAT)
+        ix = ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
+        rows, st = ctx.locate(ix, T, 0, Rd, 0.3)
+    finally:
+        ctx.set_stream(None)
+    want, wst = oracle.locator(g, mask, 0.3, reads, offs, 50, 500, nthreads=2)
+    for c in ("found", "j", "pos", "cost", "n_pairs"):
+        assert (rows[c] == want[c]).all(), c
+    assert st == wst
