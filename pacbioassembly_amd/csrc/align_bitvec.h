@@ -90,10 +90,10 @@ __device__ __forceinline__ uint32_t addc_mask(uint32_t a, uint32_t b, uint64_t c
     return d;
 }
 
-// (a | b) & c and a | b in one full-rate v_bitop3_b32 each (the compiler would pick the half-rate v_and_or_b32)
-__device__ __forceinline__ uint32_t or_and(uint32_t a, uint32_t b, uint32_t c) {
+// a | (b & c) in one full-rate v_bitop3_b32 (the compiler would pick the half-rate v_and_or_b32)
+__device__ __forceinline__ uint32_t or_of_and(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t d;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xa8" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // (a|b)&c: (0xF0|0xCC)&0xAA
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf8" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // 0xF0 | (0xCC & 0xAA)
     return d;
 }
 // sign-extended bit k of x (k wave-uniform): 0 or ~0
@@ -224,22 +224,24 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     uint64_t hn = ((hn_last << 1) | (hn_last >> 63)) & valid;
 
     // one block update (hp / hn: lane masks of the delta entering at the block's top row, replaced by the one leaving)
-#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, XH, MV_OLD)                                 \
+    // D0 (bit r set iff D(i,j) == D(i-1,j-1)) doubles as Myers' Xv in the two vertical updates (Hyyro's form of
+    // the recurrences: wherever D0 and Eq | Mv differ a carry came in from the row above, whose horizontal delta is
+    // then -1, and both forms give Pv' = 1, Mv' = 0)
+#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, D0)                                         \
     {                                                                                \
         const uint32_t Eq = ~(Plo[nb] ^ clo) & ~(Phi[nb] ^ chi);                     \
         const uint32_t pv = Pv[nb], mv = Mv[nb];                                     \
-        const uint32_t Xv = Eq | mv;                                                 \
         uint64_t unused;                                                             \
         const uint32_t sum = addc_mask(Eq & pv, pv, hn, unused);   /* hn as carry-in == Eq |= 1 at the top row */ \
         const uint32_t Xh = (sum ^ pv) | Eq;                                         \
         const uint32_t Ph = mv | ~(Xh | pv);                                         \
         const uint32_t Mh = pv & Xh;                                                 \
-        XH = Xh; MV_OLD = mv;       /* D0 = Xh | mv: bit r set iff D(i,j) == D(i-1,j-1) */ \
+        D0 = Xh | mv;                                                                \
         PH_PRE = Ph; MH_PRE = Mh;                                                    \
         const uint32_t Ph2 = addc_mask(Ph, Ph, hp, hp);                              \
         const uint32_t Mh2 = addc_mask(Mh, Mh, hn, hn);                              \
-        Pv[nb] = Mh2 | ~(Xv | Ph2);                                                  \
-        Mv[nb] = Ph2 & Xv;                                                           \
+        Pv[nb] = Mh2 | ~(D0 | Ph2);                                                  \
+        Mv[nb] = Ph2 & D0;                                                           \
     }
 
     // ------------------------------------------------------------------ phase 1: down to cell (m,m)
@@ -256,12 +258,12 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         PBA_BV_HIN();
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            uint32_t xh, mvo, php, mhp;
-            PBA_BV_BLOCK(nb, php, mhp, xh, mvo);
+            uint32_t d0, php, mhp;
+            PBA_BV_BLOCK(nb, php, mhp, d0);
             (void)php; (void)mhp;
             // keep the diagonal cell's D0 bit (garbage while the diagonal is in another block: the word is
             // cleared when the diagonal enters)
-            acc[nb] |= or_and(xh, mvo, dmw);
+            acc[nb] = or_of_and(acc[nb], d0, dmw);
         }
         hp_last = hp; hn_last = hn;
         dmw = (dmw << 1) | (dmw >> 31);
@@ -291,9 +293,9 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         uint32_t ph_m = 0, mh_m = 0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            uint32_t xh, mvo, php, mhp;
-            PBA_BV_BLOCK(nb, php, mhp, xh, mvo);
-            (void)xh; (void)mvo;
+            uint32_t d0, php, mhp;
+            PBA_BV_BLOCK(nb, php, mhp, d0);
+            (void)d0;
             if (nb == nb_m) { ph_m = php; mh_m = mhp; }
         }
         hp_last = hp; hn_last = hn;
