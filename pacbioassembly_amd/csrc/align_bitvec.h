@@ -161,7 +161,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     int score = 0, best = INT_MAX, bestj = 0, fail_row = 0;
     uint32_t dmw = 0;                            // one-hot: bit of the diagonal cell in its block's word (0: not in this lane)
     uint64_t hp_last = ~0ull, hn_last = 0ull;    // lane masks: delta +1 / -1 leaving each lane's last block in the previous step
-    int t_next = min(min(t_evt, t_seg + 1), t_dstart);   // the one rare-event compare of the step loop
+    // lanes whose first block still receives the lane above's hout (the others see "+1 per column")
+    uint64_t valid = __builtin_amdgcn_ballot_w64(1 <= t_hin_end);
+    // the one rare-event compare of the step loop
+    int t_next = min(min(t_evt, t_seg + 1), min(t_dstart, 1 <= t_hin_end ? t_hin_end + 1 : INT_MAX));
 
     // text planes for the 32 steps starting at the wave-uniform step tb (element of step t is t - s_cur - 1)
     auto load_text = [&](int tb) { load_planes32(colsF, tb - s_cur - 1, wl, wh); };
@@ -212,14 +215,14 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             dmw = 1u; t_dstart = INT_MAX;                                             \
             _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] = 0;            \
         }                                                                             \
-        t_next = min(min(t_evt, t_seg + 1), t_dstart);                                \
+        t_next = min(min(t_evt, t_seg + 1), min(t_dstart, t <= t_hin_end ? t_hin_end + 1 : INT_MAX)); \
       }                                                                               \
+      valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);   /* changes only at events: kept as a scalar mask */ \
     }
 
     // hin of each lane's first block: the lane above's hout of the previous step, rotated one lane up, where that
     // lane was still inside its window; elsewhere the row above the window counts "+1 per column"
 #define PBA_BV_HIN()                                                                  \
-    const uint64_t valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);               \
     uint64_t hp = (((hp_last << 1) | (hp_last >> 63)) & valid) | ~valid;              \
     uint64_t hn = ((hn_last << 1) | (hn_last >> 63)) & valid;
 
@@ -245,11 +248,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     }
 
     // ------------------------------------------------------------------ phase 1: down to cell (m,m)
-    int t = 1;
     bool failed = false;
-    for (; t <= t1; ++t) {
+    for (int t = 1; t <= t1; ++t) {              // t is wave-uniform and not live out of the loop: stays in an SGPR
         PBA_BV_RARE();
-        const int k = (__builtin_amdgcn_readfirstlane(t) - 1) & 31;
+        const int k = (t - 1) & 31;
         if (k == 0) {                            // wave-uniform, every 32 steps: next text planes, poll for failure
             load_text(t);
             if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; break; }
@@ -268,6 +270,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         hp_last = hp; hn_last = hn;
         dmw = (dmw << 1) | (dmw >> 31);
     }
+    int t = t1 + 1;
     if (!failed) {                               // segments that ended in the last step (the one holding row m does)
         const int above = __shfl(score, (lane + PBA_WAVE - 1) & (PBA_WAVE - 1), PBA_WAVE);
         if (t == t_seg + 1) segment_done(t, above);
@@ -280,13 +283,13 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         return __builtin_amdgcn_readfirstlane(fr);
     }
     t_seg = INT_MAX - 1; t_dstart = INT_MAX;
-    t_next = t_evt;
+    t_next = min(t_evt, t <= t_hin_end ? t_hin_end + 1 : INT_MAX);
 
     // ------------------------------------------------------------------ phase 2: goal row right of the diagonal
     const bool owner = s_cur == s_m;             // the lane holding row m
-    for (; t <= t_end; ++t) {
+    for (t = t1 + 1; t <= t_end; ++t) {
         PBA_BV_RARE();
-        const int k = (__builtin_amdgcn_readfirstlane(t) - 1) & 31;
+        const int k = (t - 1) & 31;
         if (k == 0) load_text(t);
         const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
