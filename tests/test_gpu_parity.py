@@ -393,3 +393,51 @@ def test_runs_on_a_caller_owned_stream(ctx, oracle):
     for c in ("found", "j", "pos", "cost", "n_pairs"):
         assert (rows[c] == want[c]).all(), c
     assert st == wst
+
+
+# ----------------------------------------------------------------------------- fuzz
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_align_fuzz_vs_oracle(ctx, oracle, kernel):
+    """700 random pair shapes (lengths 1..4000, related / unrelated, tails, swapped roles, all four direction
+    combinations, R from 0.05 to 0.49) through both kernels against the oracle, bit for bit."""
+    rng = np.random.RandomState(424242)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seqs, pairs, Rs = [], [], []
+    for t in range(700):
+        la = int(np.exp(rng.uniform(0, np.log(4000))))
+        a = alpha[rng.randint(0, 4, la)]
+        kind = rng.randint(0, 10)
+        if kind == 0:
+            b = alpha[rng.randint(0, 4, int(np.exp(rng.uniform(0, np.log(4000)))))]          # unrelated
+        else:
+            e = [0.0, 0.02, 0.08, 0.15, 0.15, 0.22, 0.30, 0.40, 0.15, 0.05][kind]
+            u = rng.rand(la)
+            out = []
+            for ch, x in zip(a, u):
+                if x < e / 3:
+                    out += [alpha[rng.randint(4)], ch]
+                elif x < 2 * e / 3:
+                    pass
+                elif x < e:
+                    out.append(alpha[rng.randint(4)])
+                else:
+                    out.append(ch)
+            tail = int(rng.choice([0, 0, 1, 17, 300, 2000]))
+            b = np.concatenate([np.array(out, np.uint8), alpha[rng.randint(0, 4, tail)]]).astype(np.uint8)
+        if rng.rand() < 0.35:
+            a, b = b, a
+        fa, fb = (int(rng.rand() < 0.25), int(rng.rand() < 0.25))
+        a, b = a.tobytes(), b.tobytes()
+        ia = len(seqs); seqs += [a, b]
+        pairs.append((ia, len(a) - 1 if fa and a else 0, len(a), ia + 1, len(b) - 1 if fb and b else 0, len(b), fa | (fb << 1)))
+        Rs.append(float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.3, 0.3, 0.4, 0.49])))
+    S = ctx.seqs_from_list(seqs, strict_acgt=True)
+    for R in sorted(set(Rs)):
+        sel = [q for q in range(len(pairs)) if Rs[q] == R]
+        out = ctx.align_batch(S, S, np.array([pairs[q] for q in sel], PAIR_DTYPE), R, kernel=kernel)
+        for q, got in zip(sel, out):
+            sa, pa, la_, sb, pb, lb_, fl = pairs[q]
+            a = seqs[sa][::-1] if fl & 1 else seqs[sa]          # accessor elements in order
+            b = seqs[sb][::-1] if fl & 2 else seqs[sb]
+            exp = oracle.align(a, b, R)                         # forward over the reversed copy == backward accessor
+            check_result(got, exp, (q, R, la_, lb_, fl, kernel))
