@@ -113,7 +113,10 @@ typedef struct pba_seqs pba_seqs;
 /* text: concatenated ASCII; sequence i = text[offsets[i] .. offsets[i+1]).  Bytes are packed
  * with C2I (dna_seq.h:21).  If strict_acgt != 0 a byte outside "ACGT" fails with
  * PBA_E_ALPHABET (the packed DP compares codes, the reference compares bytes: they agree
- * exactly on ACGT input).  Packing runs on the GPU. */
+ * exactly on ACGT input).  Packing runs on the GPU.  With strict_acgt == 0 such bytes are packed
+ * as code 3 (that is what the seed index of locator.cpp:62-66 sees), the set remembers it, and the
+ * aligning entry points (pba_align_batch, pba_locate, pba_spaced_round) refuse it with
+ * PBA_E_ALPHABET rather than return scores the reference would not: use pba_align_text there. */
 int pba_seqs_from_text(pba_ctx *ctx, const char *text, const uint64_t *offsets, uint32_t n,
                        int strict_acgt, pba_seqs **out);
 /* same, but text/offsets are DEVICE pointers (inputs already resident in HBM) */

@@ -35,6 +35,7 @@ struct pba_seqs {
     pba_ctx *ctx;
     uint32_t n, max_len;
     uint64_t packed_bytes;   // packed payload resident in HBM (incl. alignment padding)
+    bool non_acgt;           // some byte outside ACGT was packed as code 3 (C2I): the packed DP would match it against T
     uint8_t *d_alloc;        // allocation; d_packed = d_alloc + kSlack
     uint8_t *d_packed;
     uint64_t *d_off;
@@ -110,7 +111,7 @@ k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_of
         word |= code << (8 * (k >> 2) + 6 - 2 * (k & 3));   // byte k/4, first base in bits 7:6
     }
     *reinterpret_cast<uint32_t *>(packed + byte) = word;    // padding bytes of the last dword stay 0
-    if (strict && notacgt) atomicOr(bad, 1u);
+    if (notacgt) atomicOr(bad, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,7 +467,7 @@ static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff
                      int strict, pba_seqs **out) {
     pba_seqs *s = new (std::nothrow) pba_seqs();
     if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
-    s->ctx = ctx; s->n = n; s->max_len = 0; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->ctx = ctx; s->n = n; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
     s->h_off.resize(n + 1); s->h_len.resize(n + 1);
     uint64_t pk = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -500,6 +501,7 @@ static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "k_pack_text", e); }
     if (strict && h_bad) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_ALPHABET, "pba_seqs_from_text"); }
+    s->non_acgt = h_bad != 0;
     *out = s;
     return PBA_OK;
 }
@@ -542,7 +544,7 @@ int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, ui
     pba_open_binary(file, file_len, min_excl, max_excl, recs.data(), kept, nullptr);
     pba_seqs *s = new (std::nothrow) pba_seqs();
     if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
-    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
     s->h_off.resize(kept + 1); s->h_len.resize(kept + 1);
     for (size_t i = 0; i < kept; ++i) {
         uint32_t L;
@@ -928,6 +930,8 @@ int pba_align_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pb
     if (!ctx || !A || !B || (!pairs && n) || (!out && n)) return PBA_E_INVALID;
     if (n == 0) return PBA_OK;
     if (n > 0x7FFFFFFFull) PBA_FAIL(PBA_E_INVALID, "too many pairs in one batch");
+    if (A->non_acgt || B->non_acgt)
+        PBA_FAIL(PBA_E_ALPHABET, "a sequence set holds bytes outside ACGT: the reference compares raw bytes, use pba_align_text");
     HIPCHK(hipSetDevice(ctx->device));
     int mdmax = 1;
     for (size_t q = 0; q < n; ++q) {
@@ -1019,6 +1023,8 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     if (ix->mode != PBA_INDEX_ALL || ix->seq_len != target->h_len[target_seq])
         PBA_FAIL(PBA_E_INVALID, "pba_locate needs a PBA_INDEX_ALL index of the target sequence");
     if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
+    if (target->non_acgt || reads->non_acgt)   // locator.cpp compares raw bytes (an 'N' only matches an 'N'); codes would match it to T
+        PBA_FAIL(PBA_E_ALPHABET, "pba_locate: a sequence set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = reads->n;
     Plan pl;
@@ -1088,6 +1094,7 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
         PBA_FAIL(PBA_E_INVALID, "pba_spaced_round needs a PBA_INDEX_HEAD_TAIL index of the reference sequence");
     if (reads->max_len > (uint32_t)kMaxSeqLen || ref->h_len[ref_seq] > 0x7FFFFFF0u)
         PBA_FAIL(PBA_E_TOOLONG, "sequence longer than the engine limit");
+    if (ref->non_acgt || reads->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "pba_spaced_round: a sequence set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t n = reads->n;
     Plan pl;

@@ -367,6 +367,12 @@ def test_error_codes_not_exceptions_across_the_abi(ctx):
     with pytest.raises(PbaError) as e:
         ctx.locate(ix2, T, 0, S, 0.3)
     assert e.value.status == -1
+    # bytes outside ACGT: the index may be built (C2I codes, like the reference's), aligning is refused loudly
+    Sn = ctx.seqs_from_list([b"ACGTNACGT" * 20, b"ACGT" * 50])
+    ctx.index_build(Sn, 0, eng.mask_from_pattern(MASK_PAT), PBA_INDEX_ALL)
+    with pytest.raises(PbaError) as e:
+        ctx.align_batch(Sn, Sn, np.array([(0, 0, 100, 1, 0, 100, 0)], PAIR_DTYPE), 0.3)
+    assert e.value.status == -6
     # empty batches are fine
     assert ctx.align_batch(S, S, np.zeros(0, PAIR_DTYPE), 0.3).size == 0
     empty = ctx.seqs_from_list([])
