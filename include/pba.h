@@ -250,6 +250,34 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
                      const pba_seqs *reads, double R, int max_trial, int overlap_min, int buggy_seed_at,
                      int kernel, pba_ss_row *rows);
 
+/* ------------------------------------------------------------------------ */
+/* All-vs-all overlap.  Not a loop the reference  */
+/* has, but built only from its pieces: every read t in [t_lo, t_hi) takes the */
+/* reference role (ref_seq::get_seedmap index of t, ref_seq.h:291-311) and     */
+/* every other read q is walked like one read of a locked spaced_seed round    */
+/* (spaced_seed.cpp:420-437 with the intended seed_at): first       */
+/* success per (t, q); every successful pair is reported.                      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t target, query;         /* read ids; target = the `a` side (ref_seq.h:264) */
+    int32_t j, dir, ref_pos;       /* probe offset, +1 forward / -1 backward, hit position in the target */
+    int32_t cost, matlen_a, matlen_b;
+} pba_overlap;
+
+typedef struct {
+    uint64_t n_probe_entries;      /* probe keys indexed (2*max_trial per read, zero keys dropped) */
+    uint64_t n_candidates;         /* (target position, probe) matches */
+    uint64_t n_pairs;              /* candidate pairs handed to the banded DP (stops at the first success per pair of reads) */
+    uint64_t n_overlaps;           /* successful (target, query) pairs */
+    float scan_ms, sort_ms, walk_ms;
+} pba_overlap_stats;
+
+/* out: caller-allocated, cap entries; *n_out = overlaps found (may exceed cap: then only cap are written).
+ * Results are sorted by (target, query).  Targets shard across GPUs through [t_lo, t_hi). */
+int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, uint32_t mask, double R,
+                    int max_trial, int overlap_min, int kernel, pba_overlap *out, uint64_t cap, uint64_t *n_out,
+                    pba_overlap_stats *stats);
+
 const char *pba_strerror(int status);
 
 #ifdef __cplusplus

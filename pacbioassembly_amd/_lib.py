@@ -32,6 +32,11 @@ class PbaLocStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_reads_kept", "n_probe_hits", "n_pairs", "n_located", "n_cells")]
 
 
+class PbaOverlapStats(C.Structure):
+    _fields_ = [("n_probe_entries", C.c_uint64), ("n_candidates", C.c_uint64), ("n_pairs", C.c_uint64),
+                ("n_overlaps", C.c_uint64), ("scan_ms", C.c_float), ("sort_ms", C.c_float), ("walk_ms", C.c_float)]
+
+
 class PbaProfile(C.Structure):
     _fields_ = [("index_ms", C.c_float), ("align_ms", C.c_float), ("align_redo_ms", C.c_float),
                 ("nb_first", C.c_uint32), ("nb_redo", C.c_uint32), ("n_first", C.c_uint32), ("n_redo", C.c_uint32)]
@@ -88,6 +93,8 @@ SYMBOLS = {
     "pba_locate": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              _P, _P]),
     "pba_spaced_round": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "pba_overlap_all": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, _P,
+                                  C.c_uint64, C.POINTER(C.c_uint64), _P]),
     "pba_strerror": (C.c_char_p, [C.c_int]),
 }
 

@@ -1,0 +1,169 @@
+// overlap.h -- all-vs-all overlap driver: every read is a target in the
+// reference role (ref_seq::get_seedmap index, /root/reference/src/ref_seq.h:291-311) and every other read a
+// query walked like one read of a locked spaced_seed round (spaced_seed.cpp:262-298, 420-437): 2*max_trial
+// probes (forward at j, backward at slen-j-16), hits in the seedmap's list order, first success per
+// (target, query) wins.  All successful (target, query) pairs are reported.
+//
+// Inverted form: the PROBES are indexed (2*max_trial keys per read: small, and the object a
+// multi-GPU run all-gathers), the targets' positions are scanned against that table:
+//   k_probe_emit : one probe entry (key << 32 | probe id) per (query, j, direction), key 0 dropped
+//   (partition + sort of the entries: the seed-index builder, seed_index.h)
+//   k_ovl_scan   : one workgroup per target; every indexed position of the target in get_seedmap order looks
+//                  its key up and emits one candidate per matching probe of another read,
+//                  candidate = query << 23 | (2j + backward) << 16 | ordinal   (count pass, then fill pass)
+//   (per-target sort of the candidates: k_part_sort; 64-bit order = query, then j, forward before backward,
+//    then the seedmap's list order -- exactly the order spaced_seed tries them in)
+//   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query
+#ifndef PBA_OVERLAP_H
+#define PBA_OVERLAP_H
+
+#include "align_bitvec.h"
+#include "align_rowsweep.h"
+#include "dev_common.h"
+#include "pba.h"
+#include "seed_index.h"
+
+#define PBA_OVL_ORD_BITS 16
+#define PBA_OVL_JD_BITS 7
+#define PBA_OVL_Q_SHIFT (PBA_OVL_ORD_BITS + PBA_OVL_JD_BITS)
+
+// probe id = query * t2 + 2*j + (backward ? 1 : 0); t2 = 2 * max_trial
+__global__ void __launch_bounds__(256)
+k_probe_emit(SeqSetDev Rd, uint32_t n_reads, uint32_t t2, uint32_t mask, uint64_t *out, unsigned long long cap,
+             unsigned long long *counter) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_reads * t2) return;
+    const uint32_t q = (uint32_t)(gid / t2), jd = (uint32_t)(gid % t2);
+    const int slen = (int)Rd.len[q];
+    const int j = (int)(jd >> 1);
+    const int pos = (jd & 1) ? slen - j - 16 : j;                       // spaced_seed.cpp:426
+    if (pos < 0 || pos + 16 > slen) return;
+    const uint32_t key = window_key(Rd.packed + Rd.off[q], (uint32_t)pos, (uint32_t)slen) & mask;
+    if (!key) return;                                                   // a zero key is never in a seedmap
+    const unsigned long long o = atomicAdd(counter, 1ull);
+    if (o < cap) out[o] = (uint64_t)key << 32 | (uint32_t)gid;
+}
+
+// visiting order of ref_seq::get_seedmap for a sequence of `len` bases
+struct HeadTail {
+    int nhead, visited, tail_top;
+    __device__ __forceinline__ HeadTail(int len) {
+        const int nh = min(len - 16, 20000), nt = min(len - 20000 - 16, 20000);
+        nhead = nh > 0 ? nh : 0;
+        visited = nhead + (nt > 0 ? nt : 0);
+        tail_top = len - 16;
+    }
+    __device__ __forceinline__ int pos_of(int ord) const { return ord < nhead ? ord : tail_top - (ord - nhead); }
+};
+
+// FILL = false: cnt[t - t_lo] = candidates of target t.  FILL = true: write them at cursor[t - t_lo]++.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_ovl_scan(IndexDev probes, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2, uint32_t *cnt_or_cursor,
+           uint64_t *cand) {
+    const uint32_t tl = blockIdx.x;
+    if (tl >= n_targets) return;
+    const uint32_t t = t_lo + tl;
+    const int len = (int)Rd.len[t];
+    const uint8_t *seq = Rd.packed + Rd.off[t];
+    const HeadTail ht(len);
+    uint32_t mine = 0;
+    for (int ord = (int)threadIdx.x; ord < ht.visited; ord += (int)blockDim.x) {
+        const int pos = ht.pos_of(ord);
+        const uint32_t key = window_key(seq, (uint32_t)pos, (uint32_t)len) & probes.mask;
+        if (!key) continue;                                             // ref_seq.h:300,307
+        uint32_t beg, n;
+        ix_find(probes, key, beg, n);
+        for (uint32_t h = 0; h < n; ++h) {
+            const uint32_t pid = (uint32_t)probes.ent[beg + h];
+            const uint32_t q = pid / t2;
+            if (q == t) continue;
+            if (FILL) {
+                const uint32_t slot = atomicAdd(&cnt_or_cursor[tl], 1u);
+                cand[slot] = (uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pid % t2) << PBA_OVL_ORD_BITS | (uint32_t)ord;
+            } else {
+                ++mine;
+            }
+        }
+    }
+    if (!FILL) {
+        __shared__ uint32_t total;
+        if (threadIdx.x == 0) total = 0;
+        __syncthreads();
+        if (mine) atomicAdd(&total, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) cnt_or_cursor[tl] = total;
+    }
+}
+
+struct OvlCfg {
+    double R;
+    int overlap_min;
+    int row_cap;      // u16 cells of LDS per wavefront
+    uint32_t t2;
+};
+
+// NB1: blocks per lane of the narrow first pass, NB2: of the reference-band re-run taken in place when the
+// narrow pass cannot certify the goal row (NB1 = NB2 = 0: row sweep).
+template <int NB1, int NB2>
+__global__ void __launch_bounds__(PBA_WAVE * (NB1 ? 4 : 1), NB1 == 0 ? 1 : (NB2 <= 4 ? 5 : 3))
+k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
+           pba_overlap *out, unsigned long long cap, unsigned long long *n_out, unsigned long long *n_pairs,
+           uint32_t *queue) {
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
+    uint16_t *lds = (uint16_t *)(lds_all + (size_t)wave * cfg.row_cap * 2);
+    for (;;) {
+        const uint32_t tl = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)atomicAdd(queue, (threadIdx.x & (PBA_WAVE - 1)) == 0 ? 1u : 0u));     // see next_slot() in pba_device.hip
+        if (tl >= n_targets) break;
+        const uint32_t t = t_lo + tl;
+        const uint8_t *ref = Rd.packed + Rd.off[t];
+        const int ref_len = (int)Rd.len[t];
+        const HeadTail ht(ref_len);
+        uint32_t done_q = 0xFFFFFFFFu;
+        unsigned long long pairs = 0;
+        for (uint32_t c = cand_off[tl]; c < cand_off[tl + 1]; ++c) {
+            const uint64_t cd = cand[c];
+            const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
+            if (q == done_q) continue;                                  // first success per (target, query) already taken
+            const uint32_t jd = (uint32_t)(cd >> PBA_OVL_ORD_BITS) & ((1u << PBA_OVL_JD_BITS) - 1);
+            const int hit = ht.pos_of((int)(cd & ((1u << PBA_OVL_ORD_BITS) - 1)));
+            const int slen = (int)Rd.len[q];
+            const int j = (int)(jd >> 1);
+            const bool fwd = (jd & 1) == 0;
+            const int pos = fwd ? j : slen - j - 16;
+            const int s_off = fwd ? pos : pos + 15;                     // spaced_seed.cpp:274
+            const int s_len = fwd ? slen - s_off : s_off + 1;           // spaced_seed.cpp:275
+            if (s_len < cfg.overlap_min) continue;                      // spaced_seed.cpp:280
+            const int r_off = fwd ? hit : hit + 15;                     // spaced_seed.cpp:285
+            const int r_len = fwd ? ref_len - r_off : r_off + 1;        // ref_seq.h:284-285
+            PackedFetch fa{ref, r_off, fwd ? 1 : -1};                   // a = the target in the reference role (ref_seq.h:264)
+            PackedFetch fb{Rd.packed + Rd.off[q], s_off, fwd ? 1 : -1};
+            AlnOut o;
+            if constexpr (NB1 == 0) {
+                align_rowsweep(fa, r_len, fb, s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
+            } else {
+                align_bitvec<NB1>(fa, r_len, fb, s_len, cfg.R, 0, 0, false, lds, cfg.row_cap, o);
+                if (o.rc == PBA_RC_UNCERTIFIED) align_bitvec<NB2>(fa, r_len, fb, s_len, cfg.R, 0, 0, true, lds, cfg.row_cap, o);
+            }
+            ++pairs;
+            if (o.rc < 0 || o.matlen_a < cfg.overlap_min) continue;     // ref_seq.h:264-265
+            done_q = q;
+            // every lane calls the atomic (lane 0 adds 1): the lane-0-only form inside a persistent loop is what
+            // ROCm 7.2's clang miscompiles (tools/ubench_queue.hip)
+            const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
+            const unsigned long long slot = atomicAdd(n_out, l0 ? 1ull : 0ull);
+            if (l0) {
+                if (slot < cap) {
+                    pba_overlap *r = out + slot;
+                    r->target = (int32_t)t; r->query = (int32_t)q; r->j = j; r->dir = fwd ? 1 : -1; r->ref_pos = hit;
+                    r->cost = o.cost; r->matlen_a = o.matlen_a; r->matlen_b = o.matlen_b;
+                }
+            }
+        }
+        atomicAdd(n_pairs, (threadIdx.x & (PBA_WAVE - 1)) == 0 ? pairs : 0ull);
+    }
+}
+
+#endif

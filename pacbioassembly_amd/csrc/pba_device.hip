@@ -16,6 +16,7 @@
 #include "dev_common.h"
 #include "pba.h"
 #include "pba_internal.h"
+#include "overlap.h"
 #include "seed_index.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -1142,6 +1143,138 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
     }
 #undef K_SS
     if (n) prof_finish(ctx);
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: all-vs-all overlap
+// ---------------------------------------------------------------------------------------------
+#define PBA_OVL_CASE(N1, N2)                                                                                          \
+    hipLaunchKernelGGL((k_ovl_walk<N1, N2>), dim3(persistent_grid(ctx, nt, (N1) ? 4 : 1, lds)),                        \
+                       dim3(PBA_WAVE * ((N1) ? 4 : 1)), lds * ((N1) ? 4 : 1), ctx->stream, reads->dev(), t_lo, nt,     \
+                       d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, d_out.as<pba_overlap>(),                     \
+                       (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1, \
+                       ctx->d_queue)
+
+int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, uint32_t mask, double R,
+                    int max_trial, int overlap_min, int kernel, pba_overlap *out, uint64_t cap, uint64_t *n_out,
+                    pba_overlap_stats *stats) {
+    if (!ctx || !reads || !n_out || (!out && cap) || t_lo > t_hi || t_hi > reads->n) return PBA_E_INVALID;
+    if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
+    if (reads->n >= (1u << 24)) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: at most 2^24 reads");
+    if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
+    if (reads->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "pba_overlap_all: the read set holds bytes outside ACGT");
+    HIPCHK(hipSetDevice(ctx->device));
+    *n_out = 0;
+    pba_overlap_stats st;
+    memset(&st, 0, sizeof st);
+    const uint32_t n = reads->n, nt = t_hi - t_lo, t2 = 2u * (uint32_t)max_trial;
+    if (nt == 0 || n < 2) { if (stats) *stats = st; return PBA_OK; }
+    Plan pl;
+    int rc = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
+    if (rc != PBA_OK) return rc;
+
+    // 1. probe table: entries of every read's 2*max_trial probes, partitioned and sorted like a seed index
+    const uint64_t pcap = (uint64_t)n * t2;
+    DevBuf d_pent, d_cnt64;
+    HIPCHK(hipMalloc(&d_pent.p, sizeof(uint64_t) * (pcap + 1)));
+    HIPCHK(hipMalloc(&d_cnt64.p, 16));
+    HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 16, ctx->stream));
+    (void)hipEventRecord(ctx->ev[2], ctx->stream);
+    hipLaunchKernelGGL(k_probe_emit, dim3((uint32_t)((pcap + 255) / 256)), dim3(256), 0, ctx->stream, reads->dev(), n, t2,
+                       mask, d_pent.as<uint64_t>(), (unsigned long long)pcap, d_cnt64.as<unsigned long long>());
+    unsigned long long n_pent = 0;
+    HIPCHK(hipMemcpyAsync(&n_pent, d_cnt64.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    st.n_probe_entries = n_pent;
+    pba_index *pix = nullptr;
+    rc = pba_index_from_entries(ctx, d_pent.p, n_pent, mask, PBA_INDEX_ALL, 0, &pix);     // identity ordinal -> value: the probe id
+    if (rc != PBA_OK) return rc;
+    struct IxGuard { pba_index *p; ~IxGuard() { pba_index_destroy(p); } } guard{pix};
+
+    // 2. scan the targets' positions against the probe table: count, offsets, fill
+    DevBuf d_off, d_cur, d_cand, d_out;
+    HIPCHK(hipMalloc(&d_off.p, sizeof(uint32_t) * (nt + 1)));
+    HIPCHK(hipMalloc(&d_cur.p, sizeof(uint32_t) * (nt + 1)));
+    hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), reads->dev(), t_lo, nt, t2,
+                       d_cur.as<uint32_t>(), (uint64_t *)nullptr);
+    std::vector<uint32_t> h_cnt(nt + 1), h_off(nt + 1);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cur.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nt; ++i) { h_off[i] = (uint32_t)total; total += h_cnt[i]; }
+    if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: more than 2^32 candidates in one target range; shard it");
+    h_off[nt] = (uint32_t)total;
+    st.n_candidates = total;
+    HIPCHK(hipMalloc(&d_cand.p, sizeof(uint64_t) * (total + 1)));
+    HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_cur.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (total) {
+        hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), reads->dev(), t_lo, nt, t2,
+                           d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        // 3. per-target sort = the reference's try order inside every (target, query)
+        uint32_t biggest = 2;
+        for (uint32_t i = 0; i < nt; ++i)
+            if (h_cnt[i] <= PBA_IX_LDS_SORT_CAP) biggest = std::max(biggest, h_cnt[i]);
+        uint32_t pow2 = 2;
+        while (pow2 < biggest) pow2 <<= 1;
+        hipLaunchKernelGGL(k_part_sort, dim3(nt), dim3(256), sizeof(uint64_t) * pow2, ctx->stream, d_cand.as<uint64_t>(),
+                           d_off.as<uint32_t>());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        for (uint32_t i = 0; i < nt; ++i)
+            if (h_cnt[i] > PBA_IX_LDS_SORT_CAP) {
+                rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], h_cnt[i]);
+                if (rc != PBA_OK) return rc;
+            }
+    } else {
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+    }
+    (void)hipEventRecord(ctx->ev[4], ctx->stream);
+
+    // 4. walk: persistent wavefronts, one target at a time
+    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_overlap) * (cap + 1)));
+    HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
+    OvlCfg ocfg;
+    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
+    const size_t lds = pl.lds;
+    const int key = pl.nb1 * 10 + pl.nb2;
+    switch (key) {
+        case 0: PBA_OVL_CASE(0, 0); break;
+        case 11: PBA_OVL_CASE(1, 1); break;
+        case 12: PBA_OVL_CASE(1, 2); break;
+        case 22: PBA_OVL_CASE(2, 2); break;
+        case 23: PBA_OVL_CASE(2, 3); break;
+        case 24: PBA_OVL_CASE(2, 4); break;
+        case 34: PBA_OVL_CASE(3, 4); break;
+        case 36: PBA_OVL_CASE(3, 6); break;
+        case 46: PBA_OVL_CASE(4, 6); break;
+        case 48: PBA_OVL_CASE(4, 8); break;
+        case 68: PBA_OVL_CASE(6, 8); break;
+        default: PBA_OVL_CASE(8, 8); break;      // any pair with nb1 <= 8 and nb2 <= 8 is valid (NB only needs to be large enough)
+    }
+    (void)hipEventRecord(ctx->ev[5], ctx->stream);
+    HIPCHK(hipGetLastError());
+    unsigned long long h_cnt2[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h_cnt2, d_cnt64.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t got = std::min<uint64_t>(h_cnt2[0], cap);
+    if (got) HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_overlap) * got, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::sort(out, out + got, [](const pba_overlap &x, const pba_overlap &y) {
+        return x.target != y.target ? x.target < y.target : x.query < y.query;
+    });
+    *n_out = h_cnt2[0];
+    st.n_overlaps = h_cnt2[0];
+    st.n_pairs = h_cnt2[1];
+    (void)hipEventElapsedTime(&st.scan_ms, ctx->ev[2], ctx->ev[3]);
+    (void)hipEventElapsedTime(&st.sort_ms, ctx->ev[3], ctx->ev[4]);
+    (void)hipEventElapsedTime(&st.walk_ms, ctx->ev[4], ctx->ev[5]);
+    if (stats) *stats = st;
     return PBA_OK;
 }
 

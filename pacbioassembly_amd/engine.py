@@ -23,6 +23,7 @@ LOC_ROW_DTYPE = np.dtype([(n, "<i4") for n in
 SS_ROW_DTYPE = np.dtype([(n, "<i4") for n in
                          ("read", "found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b", "n_trials",
                           "n_pairs")])
+OVERLAP_DTYPE = np.dtype([(n, "<i4") for n in ("target", "query", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")])
 assert PAIR_DTYPE.itemsize == C.sizeof(PbaPair) and RESULT_DTYPE.itemsize == C.sizeof(PbaResult)
 assert LOC_ROW_DTYPE.itemsize == C.sizeof(PbaLocRow) and SS_ROW_DTYPE.itemsize == C.sizeof(PbaSsRow)
 
@@ -239,6 +240,22 @@ class Context:
         self.check(self.lib.pba_spaced_round(self.h, ix.h, ref.h, ref_seq, reads.h, R, max_trial, overlap_min,
                                              int(buggy_seed_at), kernel, _ptr(rows)), "spaced_round")
         return rows[:reads.count]
+
+
+def _overlap_all(self, reads, mask, R, max_trial=32, overlap_min=64, t_lo=0, t_hi=None, kernel=PBA_KERNEL_AUTO,
+                 cap=None):
+    """All-vs-all overlap of a read set (targets t_lo..t_hi); returns (overlaps sorted by (target, query), stats)."""
+    t_hi = reads.count if t_hi is None else t_hi
+    cap = cap if cap is not None else max(1, (t_hi - t_lo) * max(reads.count - 1, 1))
+    out = np.zeros(cap, OVERLAP_DTYPE)
+    n = C.c_uint64()
+    st = _lib.PbaOverlapStats()
+    self.check(self.lib.pba_overlap_all(self.h, reads.h, t_lo, t_hi, mask, R, max_trial, overlap_min, kernel, _ptr(out), cap,
+                                        C.byref(n), C.byref(st)), "overlap_all")
+    return out[:min(int(n.value), cap)], {k: getattr(st, k) for k, _ in _lib.PbaOverlapStats._fields_}
+
+
+Context.overlap_all = _overlap_all
 
 
 class SeqSet:

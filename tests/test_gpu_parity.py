@@ -447,3 +447,54 @@ def test_align_fuzz_vs_oracle(ctx, oracle, kernel):
             b = seqs[sb][::-1] if fl & 2 else seqs[sb]
             exp = oracle.align(a, b, R)                         # forward over the reversed copy == backward accessor
             check_result(got, exp, (q, R, la_, lb_, fl, kernel))
+
+
+def test_locate_ecoli_scale_genome_vs_oracle(ctx, oracle):
+    """BASELINE config 3 shape (locator.cpp path against a 4.6 Mb target; the real E. coli data cannot be
+    fetched, so a synthetic genome of that size): identical rows (nseq, pos, cost, len-j) and pair counts."""
+    g = eng.synth_genome(33, 4_600_000)
+    reads, offs, _ = eng.synth_reads(34, g, 400, 2000, 0.09, 0.045, 0.015)      # PacBio-like error mix
+    mask = eng.mask_from_pattern(MASK_PAT)
+    T = ctx.seqs_from_text(g, np.array([0, g.size], np.uint64), strict_acgt=True)
+    Rd = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    ix = ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
+    assert ix.entries > 4_500_000
+    want, wst = oracle.locator(g, mask, 0.30, reads, offs, 50, 500, nthreads=8)
+    for kernel in KERNELS:
+        rows, st = ctx.locate(ix, T, 0, Rd, 0.30, 50, 500, kernel=kernel)
+        for c in ("nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs"):
+            assert (rows[c] == want[c]).all(), (kernel, c)
+        assert st == wst
+    assert wst["n_located"] > 250 and wst["n_pairs"] > wst["n_located"]
+
+
+# ----------------------------------------------------------------------------- all-vs-all overlap
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
+    """pba_overlap_all == running the oracle's locked spaced_seed round once per target read (every read in
+    the reference role, every other read a query, intended seed_at): same successful (target, query) set, same
+    j / dir / hit position / cost / match lengths, for whole ranges and for target shards."""
+    g = eng.synth_genome(71, 9000)
+    n, rl = 64, 1300
+    reads, offs, _ = eng.synth_reads(72, g, n, rl)
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+    texts[5] = texts[5][:700]            # ragged: a short read, and one shorter than OVERLAP_MIN + 16
+    texts[9] = texts[9][:70]
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    want = []
+    for t in range(n):
+        rows = oracle.spaced_round(texts[t], mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=8)
+        for q in range(n):
+            if q != t and rows["found"][q]:
+                want.append((t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]),
+                             int(rows["matlen_a"][q]), int(rows["matlen_b"][q])))
+    assert len(want) > 100
+    S = ctx.seqs_from_list(texts, strict_acgt=True)
+    got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=kernel)
+    assert [tuple(int(x) for x in r) for r in got] == want
+    assert st["n_overlaps"] == len(want) and st["n_pairs"] >= len(want) and st["n_candidates"] >= st["n_pairs"]
+    # target shards (what ranks of a multi-GPU run do) concatenate to the same answer
+    parts = [ctx.overlap_all(S, mask, 0.30, 32, 64, t_lo=a, t_hi=b, kernel=kernel)[0] for a, b in ((0, 20), (20, 21), (21, 64))]
+    assert [tuple(int(x) for x in r) for p in parts for r in p] == want
