@@ -277,6 +277,15 @@ typedef struct {
 int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, uint32_t mask, double R,
                     int max_trial, int overlap_min, int kernel, pba_overlap *out, uint64_t cap, uint64_t *n_out,
                     pba_overlap_stats *stats);
+/* Multi-GPU form (the one exchange of SURVEY 8e): a rank emits the probe entries of ITS queries [q_lo, q_hi)
+ * into a DEVICE buffer (2*max_trial slots per query are enough), the ranks all-gather those buffers over RCCL
+ * (slots holding all-ones are padding), and every rank hands the gathered list to pba_overlap_all_probes,
+ * which is pba_overlap_all with the probe table given instead of built. */
+int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint32_t q_hi, uint32_t mask, int max_trial,
+                       void *d_entries, uint64_t cap, uint64_t *n_out);
+int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, const void *d_probe_entries,
+                           uint64_t n_probe_slots, uint32_t mask, double R, int max_trial, int overlap_min, int kernel,
+                           pba_overlap *out, uint64_t cap, uint64_t *n_out, pba_overlap_stats *stats);
 
 const char *pba_strerror(int status);
 

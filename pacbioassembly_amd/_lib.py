@@ -95,6 +95,9 @@ SYMBOLS = {
     "pba_spaced_round": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "pba_overlap_all": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, _P,
                                   C.c_uint64, C.POINTER(C.c_uint64), _P]),
+    "pba_overlap_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pba_overlap_all_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int,
+                                         C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     "pba_strerror": (C.c_char_p, [C.c_int]),
 }
 

@@ -29,10 +29,11 @@
 
 // probe id = query * t2 + 2*j + (backward ? 1 : 0); t2 = 2 * max_trial
 __global__ void __launch_bounds__(256)
-k_probe_emit(SeqSetDev Rd, uint32_t n_reads, uint32_t t2, uint32_t mask, uint64_t *out, unsigned long long cap,
-             unsigned long long *counter) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_reads * t2) return;
+k_probe_emit(SeqSetDev Rd, uint32_t q_lo, uint32_t n_queries, uint32_t t2, uint32_t mask, uint64_t *out,
+             unsigned long long cap, unsigned long long *counter) {
+    const uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lid >= (uint64_t)n_queries * t2) return;
+    const uint64_t gid = lid + (uint64_t)q_lo * t2;                       // global probe id
     const uint32_t q = (uint32_t)(gid / t2), jd = (uint32_t)(gid % t2);
     const int slen = (int)Rd.len[q];
     const int j = (int)(jd >> 1);

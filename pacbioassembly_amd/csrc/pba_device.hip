@@ -1156,10 +1156,52 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
                        (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1, \
                        ctx->d_queue)
 
+int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint32_t q_hi, uint32_t mask, int max_trial,
+                       void *d_entries, uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !reads || !d_entries || !n_out || q_lo > q_hi || q_hi > reads->n) return PBA_E_INVALID;
+    if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
+    if (reads->n >= (1u << 24)) PBA_FAIL(PBA_E_TOOLONG, "at most 2^24 reads");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t t2 = 2u * (uint32_t)max_trial;
+    const uint64_t slots = (uint64_t)(q_hi - q_lo) * t2;
+    DevBuf counter;
+    HIPCHK(hipMalloc(&counter.p, 8));
+    HIPCHK(hipMemsetAsync(counter.p, 0, 8, ctx->stream));
+    if (slots)
+        hipLaunchKernelGGL(k_probe_emit, dim3((uint32_t)((slots + 255) / 256)), dim3(256), 0, ctx->stream, reads->dev(), q_lo,
+                           q_hi - q_lo, t2, mask, (uint64_t *)d_entries, (unsigned long long)cap,
+                           counter.as<unsigned long long>());
+    unsigned long long h_n = 0;
+    HIPCHK(hipMemcpyAsync(&h_n, counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    if (h_n > cap) PBA_FAIL(PBA_E_INVALID, "pba_overlap_probes: entry buffer too small");
+    *n_out = h_n;
+    return PBA_OK;
+}
+
 int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, uint32_t mask, double R,
                     int max_trial, int overlap_min, int kernel, pba_overlap *out, uint64_t cap, uint64_t *n_out,
                     pba_overlap_stats *stats) {
-    if (!ctx || !reads || !n_out || (!out && cap) || t_lo > t_hi || t_hi > reads->n) return PBA_E_INVALID;
+    if (!ctx || !reads || !n_out) return PBA_E_INVALID;
+    if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
+    HIPCHK(hipSetDevice(ctx->device));
+    // 1. probe table of every read, built here (single-GPU form)
+    const uint64_t pcap = (uint64_t)reads->n * 2u * (uint32_t)max_trial;
+    DevBuf d_pent;
+    HIPCHK(hipMalloc(&d_pent.p, sizeof(uint64_t) * (pcap + 1)));
+    uint64_t n_pent = 0;
+    int rc = pba_overlap_probes(ctx, reads, 0, reads->n, mask, max_trial, d_pent.p, pcap, &n_pent);
+    if (rc != PBA_OK) return rc;
+    return pba_overlap_all_probes(ctx, reads, t_lo, t_hi, d_pent.p, n_pent, mask, R, max_trial, overlap_min, kernel, out, cap,
+                                  n_out, stats);
+}
+
+int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, const void *d_probe_entries,
+                           uint64_t n_probe_slots, uint32_t mask, double R, int max_trial, int overlap_min, int kernel,
+                           pba_overlap *out, uint64_t cap, uint64_t *n_out, pba_overlap_stats *stats) {
+    if (!ctx || !reads || !n_out || (!out && cap) || t_lo > t_hi || t_hi > reads->n || (!d_probe_entries && n_probe_slots))
+        return PBA_E_INVALID;
     if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
     if (reads->n >= (1u << 24)) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: at most 2^24 reads");
     if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
@@ -1174,24 +1216,15 @@ int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t
     int rc = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (rc != PBA_OK) return rc;
 
-    // 1. probe table: entries of every read's 2*max_trial probes, partitioned and sorted like a seed index
-    const uint64_t pcap = (uint64_t)n * t2;
-    DevBuf d_pent, d_cnt64;
-    HIPCHK(hipMalloc(&d_pent.p, sizeof(uint64_t) * (pcap + 1)));
+    // 1. probe table: the (gathered) probe entries, partitioned and sorted like a seed index
+    DevBuf d_cnt64;
     HIPCHK(hipMalloc(&d_cnt64.p, 16));
-    HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 16, ctx->stream));
     (void)hipEventRecord(ctx->ev[2], ctx->stream);
-    hipLaunchKernelGGL(k_probe_emit, dim3((uint32_t)((pcap + 255) / 256)), dim3(256), 0, ctx->stream, reads->dev(), n, t2,
-                       mask, d_pent.as<uint64_t>(), (unsigned long long)pcap, d_cnt64.as<unsigned long long>());
-    unsigned long long n_pent = 0;
-    HIPCHK(hipMemcpyAsync(&n_pent, d_cnt64.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipGetLastError());
-    st.n_probe_entries = n_pent;
     pba_index *pix = nullptr;
-    rc = pba_index_from_entries(ctx, d_pent.p, n_pent, mask, PBA_INDEX_ALL, 0, &pix);     // identity ordinal -> value: the probe id
+    rc = pba_index_from_entries(ctx, d_probe_entries, n_probe_slots, mask, PBA_INDEX_ALL, 0, &pix);   // identity ordinal -> value: the probe id
     if (rc != PBA_OK) return rc;
     struct IxGuard { pba_index *p; ~IxGuard() { pba_index_destroy(p); } } guard{pix};
+    st.n_probe_entries = pix->n_entries;
 
     // 2. scan the targets' positions against the probe table: count, offsets, fill
     DevBuf d_off, d_cur, d_cand, d_out;

@@ -255,7 +255,29 @@ def _overlap_all(self, reads, mask, R, max_trial=32, overlap_min=64, t_lo=0, t_h
     return out[:min(int(n.value), cap)], {k: getattr(st, k) for k, _ in _lib.PbaOverlapStats._fields_}
 
 
+def _overlap_probes(self, reads, q_lo, q_hi, mask, max_trial, d_entries_ptr, cap):
+    """Probe entries of queries [q_lo, q_hi) into a device buffer (multi-GPU exchange form); returns the count."""
+    n = C.c_uint64()
+    self.check(self.lib.pba_overlap_probes(self.h, reads.h, q_lo, q_hi, mask, max_trial, C.c_void_p(d_entries_ptr), cap,
+                                           C.byref(n)), "overlap_probes")
+    return int(n.value)
+
+
+def _overlap_all_probes(self, reads, d_entries_ptr, n_slots, mask, R, max_trial=32, overlap_min=64, t_lo=0, t_hi=None,
+                        kernel=PBA_KERNEL_AUTO, cap=None):
+    t_hi = reads.count if t_hi is None else t_hi
+    cap = cap if cap is not None else max(1, (t_hi - t_lo) * max(reads.count - 1, 1))
+    out = np.zeros(cap, OVERLAP_DTYPE)
+    n = C.c_uint64()
+    st = _lib.PbaOverlapStats()
+    self.check(self.lib.pba_overlap_all_probes(self.h, reads.h, t_lo, t_hi, C.c_void_p(d_entries_ptr), n_slots, mask, R, max_trial,
+                                               overlap_min, kernel, _ptr(out), cap, C.byref(n), C.byref(st)), "overlap_all_probes")
+    return out[:min(int(n.value), cap)], {k: getattr(st, k) for k, _ in _lib.PbaOverlapStats._fields_}
+
+
 Context.overlap_all = _overlap_all
+Context.overlap_probes = _overlap_probes
+Context.overlap_all_probes = _overlap_all_probes
 
 
 class SeqSet:

@@ -498,3 +498,13 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     # target shards (what ranks of a multi-GPU run do) concatenate to the same answer
     parts = [ctx.overlap_all(S, mask, 0.30, 32, 64, t_lo=a, t_hi=b, kernel=kernel)[0] for a, b in ((0, 20), (20, 21), (21, 64))]
     assert [tuple(int(x) for x in r) for p in parts for r in p] == want
+    # exchange form: every "rank" emits the probes of its query shard, the padded buffers are concatenated (what
+    # the RCCL all-gather produces) and the gathered table drives the same target scan
+    import torch
+    shards, cap = ((0, 22), (22, 43), (43, 64)), 22 * 64
+    gathered = torch.full((len(shards) * cap,), -1, dtype=torch.int64, device="cuda")
+    for k, (a, b) in enumerate(shards):
+        ctx.overlap_probes(S, a, b, mask, 32, gathered[k * cap:(k + 1) * cap].data_ptr(), cap)
+    torch.cuda.synchronize()
+    got2, st2 = ctx.overlap_all_probes(S, gathered.data_ptr(), gathered.numel(), mask, 0.30, 32, 64, kernel=kernel)
+    assert [tuple(int(x) for x in r) for r in got2] == want and st2["n_probe_entries"] == st["n_probe_entries"]
