@@ -25,9 +25,11 @@ __device__ __forceinline__ int wave_prefix_min(int y, int lane) {
     return y;
 }
 
+// par (nullable): one parent code per band cell (seq_aligner.h:165-175: 1 MATCH, 2 INSERT, 3 DELETE) at
+// par[i * (2*max_dst+1) + (j - i + max_dst)], for the traceback of seq_aligner.h:214-233.
 template <class FA, class FB>
 __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, double R, int maxn, int maxm,
-                               uint16_t *row, int row_cap, AlnOut &o) {
+                               uint16_t *row, int row_cap, AlnOut &o, uint8_t *par = nullptr) {
     const int lane = threadIdx.x & (PBA_WAVE - 1);
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, m = o.max_dst;
@@ -49,7 +51,7 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
             const int c = c0 + lane;
             const int j = i + c - m;
             const bool inb = c >= c_lo && c <= c_hi;
-            int v = PBA_INF;
+            int v = PBA_INF, vm = PBA_INF, vd = PBA_INF;   // best of {match, delete}; the match / delete candidates
             if (inb) {
                 if (j == 0) {
                     v = i;                              // D(i,0) = i, seq_aligner.h:140-143
@@ -58,13 +60,23 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
                     int ou = c + 1 < W ? row[c + 1] : 0xFFFF;   // D(i-1, j), only if j-i < max_dst
                     od = od == 0xFFFF ? PBA_INF : od;
                     ou = ou == 0xFFFF ? PBA_INF : ou;
-                    v = min(od + (sa != fb(j - 1)), ou + 1);
+                    vm = od + (sa != fb(j - 1));
+                    vd = ou + 1;
+                    v = min(vm, vd);
                 }
             }
             // D(i,j) = min over k <= j of v_k + (j-k): prefix-min of v_k - k, shifted back
             int y = wave_prefix_min(v - lane, lane);
             y = min(y, carry + 1);
             const int nv = y + lane;
+            if (par) {                                  // parent, in the reference's order of strict comparisons
+                int left = __shfl_up(nv, 1, PBA_WAVE);  // D(i, j-1)
+                if (lane == 0) left = carry;
+                int cost = vm, src = 1;
+                if (c > 0 && left + 1 < cost) { cost = left + 1; src = 2; }   // i-j < max_dst  <=>  c > 0
+                if (vd < cost) src = 3;                                       // j-i < max_dst is in vd (INF otherwise)
+                if (inb && j > 0) par[(size_t)i * W + c] = (uint8_t)src;
+            }
             carry = __builtin_amdgcn_readlane(nv, PBA_WAVE - 1);
             __builtin_amdgcn_wave_barrier();
             if (inb) row[c] = (uint16_t)min(nv, 0xFFFF);

@@ -202,6 +202,58 @@ k_align_bytes(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b_dir, 
     store_result(out, o);
 }
 
+// ---- traceback: full-band row sweep that also stores one parent code per band cell, then a backward walk
+__global__ void __launch_bounds__(PBA_WAVE)
+k_align_pairs_trace(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n, AlignCfg cfg, pba_result *out,
+                    uint8_t *par, const uint64_t *par_off) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const uint32_t q = blockIdx.x;
+    if (q >= n) return;
+    const pba_pair pr = pairs[q];
+    PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
+    PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+    AlnOut o;
+    align_rowsweep(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o, par + par_off[q]);
+    store_result(out + q, o);
+}
+
+__global__ void __launch_bounds__(PBA_WAVE)
+k_align_bytes_trace(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b_dir, int lb, AlignCfg cfg,
+                    pba_result *out, uint8_t *par) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    ByteFetch fa{a, a_dir}, fb{b, b_dir};
+    AlnOut o;
+    align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o, par);
+    store_result(out, o);
+}
+
+// find_path (seq_aligner.h:214-233) walked iteratively from the goal cell; one thread per pair
+__global__ void k_trace_walk(const pba_result *res, const uint8_t *par, const uint64_t *par_off, uint8_t *ops,
+                             const uint64_t *ops_off, int32_t *nedit, uint32_t n) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const pba_result r = res[q];
+    if (r.rc < 0) { nedit[q] = 0; return; }
+    const uint8_t *p = par + par_off[q];
+    uint8_t *o = ops + ops_off[q];
+    const uint64_t capq = ops_off[q + 1] - ops_off[q];
+    const int md = r.max_dst, W = 2 * md + 1;
+    int i = r.matlen_a, j = r.matlen_b;
+    uint64_t k = 0;
+    while (i > 0 || j > 0) {
+        int src;
+        if (j == 0) src = 3;                   // init_cell: (i,0) has parent DELETE, (0,j) INSERT (seq_aligner.h:140-147)
+        else if (i == 0) src = 2;
+        else src = p[(size_t)i * W + (j - i + md)];
+        if (k < capq) o[k] = (uint8_t)src;
+        ++k;
+        if (src == 1) { --i; --j; } else if (src == 2) --j; else --i;
+    }
+    const uint64_t m = k < capq ? k : capq;
+    for (uint64_t x = 0, y = m; x + 1 < y; ++x) { --y; const uint8_t t = o[x]; o[x] = o[y]; o[y] = t; }   // goal-first -> origin-first
+    nedit[q] = (int32_t)k;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels: drivers.  One wavefront per read walks the reference's ordered candidate loop and
 // stops at the first success, so the pairs it aligns are exactly the pairs the reference aligns.
@@ -394,6 +446,8 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     (void)hipFuncSetAttribute((const void *)k_part_sort, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)k_align_pairs<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)k_align_bytes, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_align_bytes_trace, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)k_align_pairs_trace, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)k_locate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)k_spaced_round<0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     *out = ctx;
@@ -1010,6 +1064,107 @@ int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b
                        b_fwd ? 1 : -1, lb, pl.cfg, d_out.as<pba_result>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+// ---- traceback
+static const uint64_t kTraceBudget = 48ull << 30;      // parent codes resident for one call
+
+static uint64_t par_bytes_of(int la, int lb, double R) {           // (len_a + 1) * (2*max_dst + 1), seq_aligner.h:94-102
+    const int md = max_dst_of(la, lb, R);
+    const int len_a = lb >= la ? la : std::min(la, lb + md);
+    return ((uint64_t)len_a + 1) * (2ull * md + 1);
+}
+
+int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b, int b_fwd, int lb, double R,
+                         int maxn, int maxm, pba_result *out, uint8_t *ops, int32_t ops_cap, int32_t *nedit) {
+    if (!ctx || !out || !nedit || la < 0 || lb < 0 || (!a && la) || (!b && lb) || (!ops && ops_cap) || ops_cap < 0)
+        return PBA_E_INVALID;
+    if (la > kMaxSeqLen || lb > kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "pba_align_text_trace");
+    HIPCHK(hipSetDevice(ctx->device));
+    Plan pl;
+    int st = make_plan(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, max_dst_of(la, lb, R), &pl);
+    if (st != PBA_OK) return st;
+    const uint64_t pb = par_bytes_of(la, lb, R);
+    if (pb > kTraceBudget) PBA_FAIL(PBA_E_NOMEM, "parent codes exceed the traceback budget");
+    const size_t oa = 0, ob = ((size_t)la + 31) & ~(size_t)15;
+    DevBuf buf, d_out, d_par, d_ops, d_off, d_ne;
+    HIPCHK(hipMalloc(&buf.p, ob + lb + 32));
+    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result)));
+    HIPCHK(hipMalloc(&d_par.p, pb + 16));
+    HIPCHK(hipMalloc(&d_ops.p, (size_t)ops_cap + 16));
+    HIPCHK(hipMalloc(&d_off.p, 4 * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&d_ne.p, sizeof(int32_t)));
+    if (la) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + oa, a_fwd ? a : a - (la - 1), la, hipMemcpyHostToDevice, ctx->stream));
+    if (lb) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + ob, b_fwd ? b : b - (lb - 1), lb, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t offs[4] = {0, (uint64_t)ops_cap, 0, 0};          // ops_off[0..1], par_off[0]
+    HIPCHK(hipMemcpyAsync(d_off.p, offs, sizeof offs, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *da = buf.as<uint8_t>() + oa + (a_fwd || !la ? 0 : la - 1);
+    const uint8_t *db = buf.as<uint8_t>() + ob + (b_fwd || !lb ? 0 : lb - 1);
+    hipLaunchKernelGGL(k_align_bytes_trace, dim3(1), dim3(PBA_WAVE), pl.lds, ctx->stream, da, a_fwd ? 1 : -1, la, db,
+                       b_fwd ? 1 : -1, lb, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>());
+    hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, ctx->stream, d_out.as<pba_result>(), d_par.as<uint8_t>(),
+                       d_off.as<uint64_t>() + 2, d_ops.as<uint8_t>(), d_off.as<uint64_t>(), d_ne.as<int32_t>(), 1u);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nedit, d_ne.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int32_t ncopy = std::min(*nedit, ops_cap);
+    if (ncopy > 0) HIPCHK(hipMemcpyAsync(ops, d_ops.p, (size_t)ncopy, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
+                          int maxn, int maxm, pba_result *out, uint8_t *ops, const uint64_t *ops_off, int32_t *nedit) {
+    if (!ctx || !A || !B || (!pairs && n) || (!out && n) || (!ops_off && n) || (!nedit && n)) return PBA_E_INVALID;
+    if (n == 0) return PBA_OK;
+    if (n > 0x7FFFFFFFull) PBA_FAIL(PBA_E_INVALID, "too many pairs in one batch");
+    if (A->non_acgt || B->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "a sequence set holds bytes outside ACGT: use pba_align_text_trace");
+    HIPCHK(hipSetDevice(ctx->device));
+    int mdmax = 1;
+    std::vector<uint64_t> par_off(n + 1, 0);
+    for (size_t q = 0; q < n; ++q) {
+        const pba_pair &p = pairs[q];
+        if (!pair_ok(A, p.a_seq, p.a_pos, p.a_len, p.flags & PBA_A_BACKWARD) ||
+            !pair_ok(B, p.b_seq, p.b_pos, p.b_len, p.flags & PBA_B_BACKWARD))
+            PBA_FAIL(PBA_E_INVALID, "pair outside its sequence (or longer than the engine limit)");
+        if (ops_off[q + 1] < ops_off[q] || ops_off[q + 1] - ops_off[q] < (uint64_t)p.a_len + p.b_len)
+            PBA_FAIL(PBA_E_INVALID, "ops_off must leave a_len + b_len slots per pair");
+        if (R > 0.0 && R < 1.0) {
+            mdmax = std::max(mdmax, max_dst_of(p.a_len, p.b_len, R));
+            par_off[q + 1] = par_off[q] + ((par_bytes_of(p.a_len, p.b_len, R) + 15) & ~15ull);
+        }
+    }
+    Plan pl;
+    int st = make_plan(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, mdmax, &pl);
+    if (st != PBA_OK) return st;
+    if (par_off[n] > kTraceBudget) PBA_FAIL(PBA_E_NOMEM, "parent codes of this batch exceed the traceback budget: split it");
+    const uint64_t ops_total = ops_off[n] - ops_off[0];
+    DevBuf d_pairs, d_out, d_par, d_poff, d_ops, d_ooff, d_ne;
+    HIPCHK(hipMalloc(&d_pairs.p, sizeof(pba_pair) * n));
+    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
+    HIPCHK(hipMalloc(&d_par.p, par_off[n] + 16));
+    HIPCHK(hipMalloc(&d_poff.p, sizeof(uint64_t) * (n + 1)));
+    HIPCHK(hipMalloc(&d_ops.p, ops_total + 16));
+    HIPCHK(hipMalloc(&d_ooff.p, sizeof(uint64_t) * (n + 1)));
+    HIPCHK(hipMalloc(&d_ne.p, sizeof(int32_t) * n));
+    std::vector<uint64_t> rel(n + 1);
+    for (size_t q = 0; q <= n; ++q) rel[q] = ops_off[q] - ops_off[0];
+    HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_poff.p, par_off.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_ooff.p, rel.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_align_pairs_trace, dim3((uint32_t)n), dim3(PBA_WAVE), pl.lds, ctx->stream, A->dev(), B->dev(),
+                       d_pairs.as<pba_pair>(), (uint32_t)n, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>(),
+                       d_poff.as<uint64_t>());
+    hipLaunchKernelGGL(k_trace_walk, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out.as<pba_result>(),
+                       d_par.as<uint8_t>(), d_poff.as<uint64_t>(), d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(),
+                       d_ne.as<int32_t>(), (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nedit, d_ne.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (ops_total) HIPCHK(hipMemcpyAsync(ops + ops_off[0], d_ops.p, ops_total, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PBA_OK;
 }

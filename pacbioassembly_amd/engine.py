@@ -224,6 +224,33 @@ class Context:
                                            len(b), R, maxn, maxm, _ptr(out)), "align_text")
         return out[0]
 
+    def align_text_trace(self, a: bytes, b: bytes, R: float, a_fwd: bool = True, b_fwd: bool = True, maxn: int = 0,
+                         maxm: int = 0):
+        """align_text plus the edit script: returns (result, ops uint8[nedit]) with 1 MATCH, 2 INSERT, 3 DELETE."""
+        abuf = np.frombuffer(a + b"\0", np.uint8)
+        bbuf = np.frombuffer(b + b"\0", np.uint8)
+        pa = abuf.ctypes.data + (0 if a_fwd or not a else len(a) - 1)
+        pb = bbuf.ctypes.data + (0 if b_fwd or not b else len(b) - 1)
+        out = np.zeros(1, RESULT_DTYPE)
+        cap = len(a) + len(b) + 1
+        ops = np.zeros(cap, np.uint8)
+        ne = C.c_int32()
+        self.check(self.lib.pba_align_text_trace(self.h, C.c_void_p(pa), int(a_fwd), len(a), C.c_void_p(pb), int(b_fwd), len(b),
+                                                 R, maxn, maxm, _ptr(out), _ptr(ops), cap, C.byref(ne)), "align_text_trace")
+        return out[0], ops[:ne.value].copy()
+
+    def align_batch_trace(self, A: "SeqSet", B: "SeqSet", pairs: np.ndarray, R: float, maxn: int = 0, maxm: int = 0):
+        """Returns (results, list of ops arrays)."""
+        pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+        out = np.zeros(pairs.size, RESULT_DTYPE)
+        off = np.zeros(pairs.size + 1, np.uint64)
+        off[1:] = np.cumsum(pairs["a_len"].astype(np.int64) + pairs["b_len"].astype(np.int64)).astype(np.uint64)
+        ops = np.zeros(int(off[-1]) + 1, np.uint8)
+        ne = np.zeros(max(pairs.size, 1), np.int32)
+        self.check(self.lib.pba_align_batch_trace(self.h, A.h, B.h, _ptr(pairs), pairs.size, R, maxn, maxm, _ptr(out), _ptr(ops),
+                                                  _ptr(off), _ptr(ne)), "align_batch_trace")
+        return out, [ops[int(off[q]):int(off[q]) + int(ne[q])].copy() for q in range(pairs.size)]
+
     # -- drivers
     def locate(self, ix: "SeedIndex", target: "SeqSet", target_seq: int, reads: "SeqSet", R: float,
                trials: int = 50, min_len: int = 500, maxn: int = 0, maxm: int = 0, kernel: int = PBA_KERNEL_AUTO):

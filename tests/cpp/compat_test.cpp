@@ -46,31 +46,43 @@ static void accessor() {               // test/dna_test.cpp:32-60
     CHECK('T' == db.next()); CHECK('G' == db.next()); CHECK(!db.has_more());
 }
 
+// test/aligner_test.cpp:29-41: replaying edits[] against the reference string must reproduce it
+template <class AL>
+static void edit_tester(seq_accessor *pref, AL *pal) {
+    int j = 0;
+    for (int i = 0; i < pal->nedit; ++i) {
+        char op = pal->edits[i].op;
+        if (op == MATCH || op == INSERT) { CHECK(pref->at(j) == pal->edits[i].val); ++j; }
+    }
+}
+
 static void aligner(const char *real_align_path) {   // test/aligner_test.cpp:44-117 (score expectations)
     char dna_ref[] = "ACGTAACCGGTT", dna_seg1[] = "CGTAAGC", dna_seg2[] = "GTAACGGGTTAA", dna_seg3[] = "TCGTAAC";
     t_aligner *pal = new t_aligner();
     {
         seq_accessor ref1(dna_ref, true, 7), seg1(dna_seg1, true, 6);
         int rc = pal->align(&seg1, &ref1);
-        CHECK(6 <= rc && rc <= 7); CHECK(2 == pal->final_cost());
+        CHECK(6 <= rc && rc <= 7); CHECK(2 == pal->final_cost()); edit_tester(&ref1, pal);
         seq_accessor ref2(dna_ref, true, 8), seg2(dna_seg1, true, 7);
-        CHECK(7 == pal->align(&seg2, &ref2)); CHECK(2 == pal->final_cost());
+        CHECK(7 == pal->align(&seg2, &ref2)); CHECK(2 == pal->final_cost()); edit_tester(&ref2, pal);
         seq_accessor ref3(dna_ref, true, 8), seg3(dna_seg3, true, 7);
-        CHECK(7 == pal->align(&seg3, &ref3)); CHECK(1 == pal->final_cost());
+        CHECK(7 == pal->align(&seg3, &ref3)); CHECK(1 == pal->final_cost()); edit_tester(&ref3, pal);
     }
     {   // backward
         seq_accessor ref(dna_ref + 7, false, 7), seg(dna_seg1 + 6, false, 7);
-        CHECK(7 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost());
+        CHECK(7 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost()); edit_tester(&ref, pal);
     }
     {   // overlay
         seq_accessor ref(dna_ref + 2, true, 10), seg(dna_seg2, true, 12);
-        CHECK(10 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost());
+        CHECK(10 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost()); edit_tester(&ref, pal);
     }
-    {   // remove (nedit / edits[] belong to the traceback row, not checked here)
+    {   // remove: test/aligner_test.cpp:82-98
         seq_accessor ref(dna_ref, true, 10), seg(dna_ref + 1, true, 9);
-        CHECK(10 == pal->align(&seg, &ref)); CHECK(1 == pal->final_cost());
+        CHECK(10 == pal->align(&seg, &ref)); CHECK(10 == pal->nedit); CHECK(INSERT == pal->edits[0].op);
+        CHECK(1 == pal->final_cost()); edit_tester(&ref, pal);
         ref.reset(0); seg.reset(0);
-        CHECK(9 == pal->align(&ref, &seg)); CHECK(1 == pal->final_cost());
+        CHECK(9 == pal->align(&ref, &seg)); CHECK(10 == pal->nedit); CHECK(DELETE == pal->edits[0].op);
+        CHECK(1 == pal->final_cost()); edit_tester(&seg, pal);
     }
     {   // sample: real reads
         std::ifstream fin(real_align_path);
@@ -79,8 +91,8 @@ static void aligner(const char *real_align_path) {   // test/aligner_test.cpp:44
         CHECK(ref_str.size() == 736);
         seq_accessor ref((char *)ref_str.c_str() + ref_str.length() - 1, false, ref_str.length());
         seq_accessor seg((char *)seg_str.c_str() + seg_str.length() - 1, false, seg_str.length());
-        CHECK(0 < pal->align(&seg, &ref));
-        CHECK(736 == pal->matlen_a && 736 == pal->matlen_b && 7 == pal->final_cost());
+        CHECK(0 < pal->align(&seg, &ref)); edit_tester(&ref, pal);
+        CHECK(736 == pal->matlen_a && 736 == pal->matlen_b && 7 == pal->final_cost() && 739 == pal->nedit);
         fin >> ref_str >> seg_str;
         seq_accessor ref2((char *)ref_str.c_str(), true, ref_str.length());
         seq_accessor seg2((char *)seg_str.c_str(), true, seg_str.length());

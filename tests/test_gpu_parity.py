@@ -178,6 +178,40 @@ def test_align_random_vs_oracle(ctx, oracle, kernel):
         assert n_ok >= 48          # the test is not vacuous: plenty of successful alignments
 
 
+# ----------------------------------------------------------------------------- traceback
+def test_traceback_golden_and_oracle(ctx, oracle):
+    """edits[] / nedit (seq_aligner.h:214-233): every golden case through pba_align_text_trace (digest of the whole
+    script produced by the reference), and the ACGT ones through the packed batch form against the oracle."""
+    import hashlib
+    cases = gold_json("align_kat.json")
+    for c in cases:
+        r, ops = ctx.align_text_trace(c["a"].encode("latin1"), c["b"].encode("latin1"), c["R"], c["a_fwd"], c["b_fwd"])
+        check_result(r, c["exp"], c["tag"])
+        if c["exp"]["rc"] >= 0:
+            assert ops.size == c["exp"]["nedit"], c["tag"]
+            assert (int(ops[0]) if ops.size else 0) == c["exp"]["first_op"], c["tag"]
+            assert hashlib.sha256(bytes(ops)).hexdigest()[:24] == c["exp"]["ops_sha"], c["tag"]
+        else:
+            assert ops.size == 0
+    sub = [c for c in cases if set(c["a"] + c["b"]) <= set("ACGT") and c["R"] == 0.3]
+    seqs, pairs = pairs_for(sub)
+    S = ctx.seqs_from_list(seqs, strict_acgt=True)
+    out, scripts = ctx.align_batch_trace(S, S, pairs, 0.3)
+    for c, got, ops in zip(sub, out, scripts):
+        check_result(got, c["exp"], c["tag"])
+        exp = oracle.align(c["a"].encode(), c["b"].encode(), 0.3, c["a_fwd"], c["b_fwd"], want_ops=True)
+        assert ops.tolist() == exp["ops"].tolist(), c["tag"]
+    # a mid-size true overlap: script length and content against the oracle
+    g = eng.synth_genome(5, 30000)
+    reads, offs, starts = eng.synth_reads(6, g, 4, 3000)
+    for r in range(4):
+        a = reads[int(offs[r]):int(offs[r + 1])].tobytes(); b = g[int(starts[r]):int(starts[r]) + 4000].tobytes()
+        res, ops = ctx.align_text_trace(a, b, 0.3)
+        exp = oracle.align(a, b, 0.3, want_ops=True)
+        check_result(res, exp, r)
+        assert ops.tolist() == exp["ops"].tolist()
+
+
 # ----------------------------------------------------------------------------- drivers
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", ["cfg1_R30", "cfg1_R15", "cfg1_pacbio", "short_mix", "r15k_R30", "r15k_R15"])

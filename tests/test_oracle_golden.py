@@ -46,6 +46,7 @@ def test_align_kats(oracle):
         if c["exp"]["rc"] >= 0:
             assert got["nedit"] == c["exp"]["nedit"], c["tag"]
             assert (int(got["ops"][0]) if got["nedit"] else 0) == c["exp"]["first_op"], c["tag"]
+            assert hashlib.sha256(bytes(got["ops"])).hexdigest()[:24] == c["exp"]["ops_sha"], c["tag"]   # whole edit script
 
 
 def test_aligner_test_expectations(oracle):
