@@ -168,23 +168,32 @@ def main():
     index_ms = float(np.mean([p["index_ms"] for p in profs]))
     algo_bytes = st["n_pairs"] * bytes_per_pair
     achieved = algo_bytes / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")      # HBM bytes per launch from a separate --pmc run
+    traffic, pmc = None, {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")      # per-launch PMC figures from separate --pmc runs
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_locate_hbm_bytes_per_launch")
+            pmc = json.load(open(tpath))
+            traffic = pmc.get("k_locate_hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic, pmc = None, {}
     roofline = {"bound": "hbm", "kernel": f"k_locate<{profs[-1]['nb_first']}>", "achieved": round(achieved, 3),
                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6),
                 "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(align_ms, 3),
                 "note": "score-only banded DP keeps its state in registers: HBM is not what bounds it (SURVEY 8d "
                         "expects <<1 %); the binding resource is integer VALU issue, see roofline_valu"}
     gcups = st["n_cells"] / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
-    roofline_valu = {"bound": "valu-int32", "achieved_gcups": round(gcups, 1),
-                     "note": "reference-equivalent band cells per second of the first k_locate launch; the "
-                             "bit-vector kernel evaluates 32 cells per ~20 lane-ops",
-                     "peak_lane_ops_per_s": INT_LANE_OPS_PEAK}
+    # VALU issue roofline: wave64 instructions per second against the measured full-rate issue (one every 2.5 cycles
+    # per SIMD, tools/ubench_ops.hip); the instruction count comes from the committed PMC run of this same command
+    valu_peak = 256 * 4 * 2.4e9 / 2.5
+    valu_insts = pmc.get("valu_insts_per_launch")
+    valu_rate = valu_insts / (align_ms * 1e-3) if valu_insts and align_ms > 0 else None
+    roofline_valu = {"bound": "valu-issue", "achieved": round(valu_rate / 1e9, 1) if valu_rate else None,
+                     "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instr/s",
+                     "frac": round(valu_rate / valu_peak, 4) if valu_rate else None,
+                     "achieved_gcups": round(gcups, 1),
+                     "note": "every instruction priced at the full rate (a lower bound on pipe occupancy: ~22 % of the "
+                             "step's instructions are half-rate v_addc_co / v_bfe / v_alignbit); gcups = reference-band "
+                             "cells per second of the first k_locate launch"}
 
     # ---- CPU baseline: the faithful oracle on this box's host cores, bounded sample of the same workload
     cpu = None

@@ -1,0 +1,80 @@
+"""Pin oracle/pba_oracle.c directly against the reference compiled from /root/reference (oracle/_ref/libpba_ref.so)
+on FRESH random inputs, beyond the committed goldens.  Only where that library exists (the build container)."""
+import numpy as np
+import pytest
+
+from oraclelib import Ref, have_ref
+from pacbioassembly_amd import engine as eng
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libpba_ref.so is built only where /root/reference exists")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return Ref()
+
+
+def test_codec_random(oracle, ref):
+    rng = np.random.RandomState(1)
+    for _ in range(200):
+        n = int(rng.randint(0, 200))
+        s = bytes(rng.choice(list(b"ACGTNacgt\n"), n).astype(np.uint8))
+        assert oracle.text2bin(s) == ref.text2bin(s) == eng.text2bin(s)
+        if n >= 16:
+            assert oracle.encode(s[:16]) == ref.encode(s[:16]) == eng.encode(s[:16])
+    t = bytes(rng.choice(list(b"ACGT"), 300).astype(np.uint8))
+    rec = oracle.text2bin(t)
+    for pos in range(0, 64):
+        assert oracle.seed_at(rec, pos) == ref.seed_at(rec, pos) == eng.seed_at(rec, pos)
+
+
+def test_align_random_full_scripts(oracle, ref):
+    """rc, cost, match lengths, nedit and the whole edit script, for shapes the goldens do not contain."""
+    rng = np.random.RandomState(2)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    for t in range(150):
+        la = int(rng.randint(1, 700))
+        a = alpha[rng.randint(0, 4, la)]
+        e = float(rng.choice([0.0, 0.1, 0.2, 0.35]))
+        keep = rng.rand(la) > e / 2
+        b = a[keep].copy()
+        flip = rng.rand(b.size) < e / 2
+        b[flip] = alpha[rng.randint(0, 4, int(flip.sum()))]
+        b = np.concatenate([b, alpha[rng.randint(0, 4, int(rng.choice([0, 5, 150])))]])
+        if rng.rand() < 0.4:
+            a, b = b, a
+        R = float(rng.choice([0.1, 0.3, 0.45]))
+        fwd = bool(rng.rand() < 0.6)
+        x = oracle.align(a.tobytes(), b.tobytes(), R, fwd, fwd, want_ops=True)
+        y = ref.align(a.tobytes(), b.tobytes(), R, fwd, fwd, want_ops=True)
+        assert x["rc"] == y["rc"] and (x["len_a"], x["len_b"], x["max_dst"]) == (y["len_a"], y["len_b"], y["max_dst"])
+        if y["rc"] >= 0:
+            assert (x["cost"], x["matlen_a"], x["matlen_b"], x["nedit"]) == (y["cost"], y["matlen_a"], y["matlen_b"], y["nedit"])
+            assert x["ops"].tolist() == y["ops"].tolist()
+
+
+def test_stock_aligner_agrees_where_well_defined(oracle, ref):
+    """The stock seq_aligner<26000,6000> typedef (no wide MAXM) agrees with the canonical one when 2*max_dst+1 <= MAXM."""
+    g = eng.synth_genome(8, 40000)
+    reads, offs, starts = eng.synth_reads(9, g, 6, 4000)
+    for r in range(6):
+        a = reads[int(offs[r]):int(offs[r + 1])].tobytes(); b = g[int(starts[r]):int(starts[r]) + 6000].tobytes()
+        x, y = ref.align(a, b, 0.3), ref.align(a, b, 0.3, stock=True)
+        assert x == y == {k: oracle.align(a, b, 0.3)[k] for k in x}
+
+
+def test_index_and_locator_random(oracle, ref):
+    mask = eng.mask_from_pattern("11*11*1*1*11*111")
+    g = eng.synth_genome(10, 60000)
+    k1, p1, rv1, nk1 = oracle.index(g.tobytes(), mask, "head_tail")
+    k2, p2, rv2, nk2 = ref.get_seedmap(g.tobytes(), mask)
+    assert (k1 == k2).all() and (p1 == p2).all() and (rv1, nk1) == (rv2, nk2)
+    k1, p1, _, _ = oracle.index(g.tobytes()[:7000], mask, "all")
+    k2, p2 = ref.locator_index(g.tobytes()[:7000], mask)
+    assert (k1 == k2).all() and (p1 == p2).all()
+    reads, offs, _ = eng.synth_reads(11, g, 120, 800, 0.09, 0.045, 0.015)
+    r1, s1 = oracle.locator(g, mask, 0.25, reads, offs, 40, 500, nthreads=4)
+    r2, s2 = ref.locator(g, mask, 0.25, reads, offs, 40, 500)
+    for c in r1.dtype.names:
+        assert (r1[c] == r2[c]).all(), c
+    assert all(s1[k] == s2[k] for k in s2)
