@@ -96,6 +96,13 @@ __device__ __forceinline__ uint32_t or_of_and(uint32_t a, uint32_t b, uint32_t c
     asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf8" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // 0xF0 | (0xCC & 0xAA)
     return d;
 }
+// ~a & ~(b ^ c): the match mask of a block from one xor and one bitop3 (left to itself the compiler rebuilds
+// Eq & Pv from the two xors separately, one instruction more per block)
+__device__ __forceinline__ uint32_t eq_mask(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x09" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // ~0xF0 & ~(0xCC ^ 0xAA)
+    return d;
+}
 // sign-extended bit k of x (k wave-uniform): 0 or ~0
 __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
     uint32_t d;
@@ -232,7 +239,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     // then -1, and both forms give Pv' = 1, Mv' = 0)
 #define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, D0)                                         \
     {                                                                                \
-        const uint32_t Eq = ~(Plo[nb] ^ clo) & ~(Phi[nb] ^ chi);                     \
+        const uint32_t Eq = eq_mask(Plo[nb] ^ clo, Phi[nb], chi);                    \
         const uint32_t pv = Pv[nb], mv = Mv[nb];                                     \
         uint64_t unused;                                                             \
         const uint32_t sum = addc_mask(Eq & pv, pv, hn, unused);   /* hn as carry-in == Eq |= 1 at the top row */ \
