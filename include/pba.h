@@ -211,16 +211,19 @@ int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int a_len, const char
 
 /* Traceback (seq_aligner.h:115-116, 214-233): the same alignment plus its edit script, ops[k] = 1 MATCH,
  * 2 INSERT, 3 DELETE in the order seq_aligner::edits[] holds them (the `val` of a MATCH / INSERT is the b
- * element it consumes, which the caller can read off b while replaying the ops).  Runs the full-band row
- * sweep and keeps one parent code per band cell in HBM ((len_a+1) * (2*max_dst+1) bytes per pair), so it is
- * meant for the pairs whose script is wanted (consensus, display), not for screening. */
+ * element it consumes, which the caller can read off b while replaying the ops).
+ * Text form: raw bytes, full-band row sweep with one parent code per band cell in HBM
+ * ((len_a+1) * (2*max_dst+1) bytes): for single pairs (display, the compat seq_aligner). */
 int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int a_len, const char *b, int b_fwd, int b_len,
                          double R, int maxn, int maxm, pba_result *out, uint8_t *ops, int32_t ops_cap, int32_t *nedit);
-/* batch form on packed sets: pair q's script goes to ops[ops_off[q] .. ops_off[q+1]) (needs a_len + b_len
- * slots), its length to nedit[q] (0 when rc < 0) */
+/* Batch form on packed sets: pair q's script goes to ops[ops_off[q] .. ops_off[q+1]) (needs a_len + b_len
+ * slots), its length to nedit[q] (0 when rc < 0).  kernel: PBA_KERNEL_AUTO / _BITVEC run the bit-vector array
+ * and stream 2 parent bits per processed cell into a per-wavefront scratch area that the same wavefront walks
+ * back (HBM-bound: ~27 MB written per 15 kb pair, any batch size); PBA_KERNEL_ROWSWEEP keeps one parent byte
+ * per band cell for every pair of the batch at once (135 MB per 15 kb pair; the cross-check). */
 int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n,
-                          double R, int maxn, int maxm, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
-                          int32_t *nedit);
+                          double R, int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops,
+                          const uint64_t *ops_off, int32_t *nedit);
 
 /* ------------------------------------------------------------------------ */
 /* Drivers: the reference's ordered first-success loops, run on the GPU.    */

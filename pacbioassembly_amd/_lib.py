@@ -92,7 +92,7 @@ SYMBOLS = {
     "pba_align_text": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P]),
     "pba_align_text_trace": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P,
                                        C.c_int32, C.POINTER(C.c_int32)]),
-    "pba_align_batch_trace": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_double, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "pba_align_batch_trace": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "pba_locate": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              _P, _P]),
     "pba_spaced_round": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

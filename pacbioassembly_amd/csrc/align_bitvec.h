@@ -119,9 +119,17 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 // masks in SGPR pairs), and the lane-to-lane hand-off of those deltas is a SCALAR rotate of the two masks -- no
 // DPP, no VALU.  The diagonal's D0 bits are collected with one bitop3 per block and a rotating one-hot; text
 // elements come from two 32-step bit-plane registers.  Everything rare sits behind one compare (t == t_next).
-template <int NB>
+//
+// TRACE: also store, for every step and block, the two words the traceback needs (bv_trace_walk below):
+//   word 0 = Eq | ~D0   bit r set: the cell's parent is the diagonal one (seq_aligner.h:164-166: MATCH wins ties)
+//   word 1 = Ph (horizontal +1 entering the cell from the left), or the new Pv (vertical +1) when the rows are
+//            the reference's b (`swap_roles`): set = the reference's INSERT, clear = its DELETE, for cells whose
+//            parent is not diagonal (INSERT is tried first and wins the tie, seq_aligner.h:167-173)
+// at tr[((t-1) * NB + nb) * 128 + word * 64 + lane]: 256 contiguous bytes per store instruction.
+template <int NB, bool TRACE = false>
 __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int w,
-                                           double R, int &best_out, int &bestj_out) {
+                                           double R, int &best_out, int &bestj_out, uint32_t *tr = nullptr,
+                                           bool swap_roles = false) {
     constexpr int RB = 32 * NB;                 // rows per superblock
     const int lane = threadIdx.x & (PBA_WAVE - 1);
     m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);   // wave-uniform by construction
@@ -237,9 +245,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     // D0 (bit r set iff D(i,j) == D(i-1,j-1)) doubles as Myers' Xv in the two vertical updates (Hyyro's form of
     // the recurrences: wherever D0 and Eq | Mv differ a carry came in from the row above, whose horizontal delta is
     // then -1, and both forms give Pv' = 1, Mv' = 0)
-#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, D0)                                         \
+#define PBA_BV_BLOCK(nb, PH_PRE, MH_PRE, D0, EQ)                                     \
     {                                                                                \
         const uint32_t Eq = eq_mask(Plo[nb] ^ clo, Phi[nb], chi);                    \
+        EQ = Eq;                                                                     \
         const uint32_t pv = Pv[nb], mv = Mv[nb];                                     \
         uint64_t unused;                                                             \
         const uint32_t sum = addc_mask(Eq & pv, pv, hn, unused);   /* hn as carry-in == Eq |= 1 at the top row */ \
@@ -254,6 +263,11 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         Mv[nb] = Ph2 & D0;                                                           \
     }
 
+    // TRACE: this lane's slot of step t, block 0, word 0.  Recomputed from t every step: a pointer carried through
+    // the loop loses its increment on the text-refill path of the step loop (ROCm 7.2 clang, seen in the ISA)
+    uint32_t *const tr_lane = tr + lane;
+    (void)tr_lane;
+#define PBA_BV_TRP() (tr_lane + (size_t)(t - 1) * (NB * 128))
     // ------------------------------------------------------------------ phase 1: down to cell (m,m)
     bool failed = false;
     for (int t = 1; t <= t1; ++t) {              // t is wave-uniform and not live out of the loop: stays in an SGPR
@@ -267,9 +281,14 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         PBA_BV_HIN();
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            uint32_t d0, php, mhp;
-            PBA_BV_BLOCK(nb, php, mhp, d0);
-            (void)php; (void)mhp;
+            uint32_t d0, php, mhp, eq;
+            PBA_BV_BLOCK(nb, php, mhp, d0, eq);
+            (void)php; (void)mhp; (void)eq;
+            if constexpr (TRACE) {
+                uint32_t *const trp = PBA_BV_TRP();
+                trp[nb * 128] = eq | ~d0;
+                trp[nb * 128 + 64] = swap_roles ? Pv[nb] : php;
+            }
             // keep the diagonal cell's D0 bit (garbage while the diagonal is in another block: the word is
             // cleared when the diagonal enters)
             acc[nb] = or_of_and(acc[nb], d0, dmw);
@@ -303,10 +322,15 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         uint32_t ph_m = 0, mh_m = 0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            uint32_t d0, php, mhp;
-            PBA_BV_BLOCK(nb, php, mhp, d0);
-            (void)d0;
+            uint32_t d0, php, mhp, eq;
+            PBA_BV_BLOCK(nb, php, mhp, d0, eq);
+            (void)d0; (void)eq;
             if (nb == nb_m) { ph_m = php; mh_m = mhp; }
+            if constexpr (TRACE) {
+                uint32_t *const trp = PBA_BV_TRP();
+                trp[nb * 128] = eq | ~d0;
+                trp[nb * 128 + 64] = swap_roles ? Pv[nb] : php;
+            }
         }
         hp_last = hp; hn_last = hn;
         if (owner) {                             // D(m,j) = D(m,j-1) + horizontal delta at row m (seq_aligner.h:202-211)
@@ -315,6 +339,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         }
     }
 #undef PBA_BV_BLOCK
+#undef PBA_BV_TRP
 #undef PBA_BV_HIN
 #undef PBA_BV_RARE
     // v_readlane: the results are wave-uniform and the compiler must know it, or every loop that depends on

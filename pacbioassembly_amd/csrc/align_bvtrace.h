@@ -1,0 +1,164 @@
+// align_bvtrace.h -- edit scripts (seq_aligner<>::find_path, /root/reference/src/seq_aligner.h:214-233) on the
+// bit-vector array: the HBM-bound tier of the aligner.
+//
+// The forward pass is bitvec_pass<NB, TRACE = true> (align_bitvec.h): the same sweep as the score-only kernel,
+// which also streams two words per (step, block, lane) into a per-wavefront scratch area -- 2 bits per DP
+// cell, 256 contiguous bytes per store instruction.  The parent of a cell, decided by the reference with strict
+// comparisons in the order MATCH, INSERT, DELETE (seq_aligner.h:164-173), is a function of the cell's delta bits:
+//   * Eq                     -> diagonal (cost D(i-1,j-1) is a lower bound of the cell, MATCH is tried first)
+//   * !Eq, D0 = 0            -> diagonal (a substitution; the cell is D(i-1,j-1)+1 and nothing is strictly cheaper)
+//   * !Eq, D0 = 1            -> the cell equals D(i-1,j-1) < the diagonal candidate; INSERT (from D(i,j-1)) if the
+//                               horizontal delta into the cell is +1, else DELETE -- INSERT wins when both are
+//                               optimal because DELETE must be strictly cheaper than INSERT
+// With the rows holding the reference's b (len_a > len_b: the array works on the transposed matrix) the
+// reference's "horizontal" is the array's vertical: the stored bit is then the new Pv instead of Ph.
+// Every cell of the traced path costs <= final_cost <= w (a certified pass) or < max_dst (the reference-band
+// pass), so its three predecessors are cells where the array's values equal the reference's and
+// the path never leaves the processed windows.
+//
+// The walk runs on the same wavefront right after the forward pass: scalar control, 64 steps of one
+// (lane, block) column of the scratch area fetched per round trip (one step per lane), ops collected 64 at a
+// time and written goal-first to a temporary, then copied out reversed.
+#ifndef PBA_ALIGN_BVTRACE_H
+#define PBA_ALIGN_BVTRACE_H
+
+#include "align_bitvec.h"
+
+// scratch words a traced pass needs: steps * NB blocks * 2 words * 64 lanes
+__device__ __host__ inline uint64_t bv_trace_words(int nb, int m, int n, int w) {
+    const int rb = 32 * nb;
+    const int S = (m + rb - 1) / rb;
+    const long long hi_last = (long long)(S - 1) * rb + rb + w;
+    const long long t_end = (hi_last < n ? hi_last : n) + (S - 1);
+    return (uint64_t)(t_end > 0 ? t_end : 0) * (uint64_t)nb * 128u;
+}
+
+// The walk reads what OTHER LANES OF THE SAME WAVEFRONT stored: same CU, same vector L1 (write-through, shared
+// by the CU), so plain loads behind a workgroup-scope fence (the stores have completed) are coherent.  Agent-scope
+// (sc1) loads are not the tool here: they are served past this XCD's L2, which still holds the lines dirty.
+__device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t ld_coherent_u8(const uint8_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ops leave the walk goal-first, 64 at a time: lane (k & 63) keeps op k until the group is full
+struct OpSink {
+    uint8_t *tmp;
+    int k;
+    uint32_t pend;
+    __device__ __forceinline__ void put(int op) {        // op is wave-uniform
+        const int lane = threadIdx.x & (PBA_WAVE - 1);
+        if (lane == (k & (PBA_WAVE - 1))) pend = (uint32_t)op;
+        ++k;
+        if ((k & (PBA_WAVE - 1)) == 0) tmp[k - PBA_WAVE + lane] = (uint8_t)pend;
+    }
+    __device__ __forceinline__ void flush() {
+        const int lane = threadIdx.x & (PBA_WAVE - 1);
+        if (lane < (k & (PBA_WAVE - 1))) tmp[(k & ~(PBA_WAVE - 1)) + lane] = (uint8_t)pend;
+    }
+};
+
+// (ri, cj): the goal cell in array coordinates (rows = the shorter sequence).  Returns with the ops of the path
+// down to a border cell in `sink`; ri / cj hold that border cell.
+template <int NB>
+__device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &cj, bool swap_roles, OpSink &sink) {
+    constexpr int RB = 32 * NB;
+    const int lane = threadIdx.x & (PBA_WAVE - 1);
+    while (ri > 0 && cj > 0) {
+        const int s = (ri - 1) / RB, ln = s & (PBA_WAVE - 1), nb = ((ri - 1) - s * RB) >> 5;
+        const int row_lo = s * RB + nb * 32;               // this word holds rows row_lo+1 .. row_lo+32
+        const int tt = cj + s - lane;                      // lane d looks at the step d before the cell's
+        uint32_t wm = 0, wh = 0;
+        if (tt >= 1) {
+            const uint32_t *p = tr + ((size_t)(tt - 1) * NB + nb) * 128 + ln;
+            wm = ld_coherent(p);
+            wh = ld_coherent(p + 64);
+        }
+        int d = 0;
+        do {
+            const int bit = (ri - 1) & 31;
+            const uint32_t mbit = ((uint32_t)__builtin_amdgcn_readlane((int)wm, d) >> bit) & 1u;
+            const uint32_t hbit = ((uint32_t)__builtin_amdgcn_readlane((int)wh, d) >> bit) & 1u;
+            if (mbit) {                                    // MATCH: (i-1, j-1)
+                sink.put(1); --ri; --cj; ++d;
+            } else {
+                sink.put(hbit ? 2 : 3);                    // INSERT : DELETE
+                if ((hbit != 0) != swap_roles) { --cj; ++d; }   // the array's column moves
+                else --ri;                                      // the array's row moves (same step, next bit down)
+            }
+        } while (ri > row_lo && cj > 0 && d < PBA_WAVE);
+    }
+}
+
+// One pair with its edit script.  NB1: blocks per lane of the narrow first pass, NB2 of the reference-band
+// re-run taken in place when the narrow pass cannot certify the goal row.
+// scratch: cap_words u32 of this wavefront's own; tmp: >= la + lb + 64 bytes of this wavefront's own.
+// ops_out receives min(nedit, ops_cap) ops in the reference's order (origin first); nedit = 0 unless o.rc >= 0.
+template <int NB1, int NB2>
+__device__ __forceinline__ void align_bitvec_trace(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
+                                                   int maxn, int maxm, uint16_t *lds, int lds_cells, uint32_t *scratch,
+                                                   uint64_t cap_words, uint8_t *tmp, uint8_t *ops_out, uint64_t ops_cap,
+                                                   AlnOut &o, int &nedit) {
+    const int lane = threadIdx.x & (PBA_WAVE - 1);
+    nedit = 0;
+    aln_params(la, lb, R, o);
+    const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
+    if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return;      // seq_aligner.h:104-107
+    const bool swap = len_a > len_b;
+    const int m = swap ? len_b : len_a, n = swap ? len_a : len_b;
+    OpSink sink{tmp, 0, 0u};
+    if (m <= 10) {
+        // the row sweep's corner (align_bitvec.h): one parent code per band cell in the scratch area
+        const int W = 2 * md + 1;
+        if ((uint64_t)(len_a + 1) * (uint64_t)W > cap_words * 4) { o.rc = -2; return; }
+        uint8_t *par = (uint8_t *)scratch;
+        align_rowsweep(fa, la, fb, lb, R, maxn, maxm, lds, lds_cells, o, par);
+        if (o.rc < 0) return;
+        wave_mem_fence();
+        int i = o.matlen_a, j = o.matlen_b;
+        while (i > 0 || j > 0) {
+            // init_cell: (i,0) has parent DELETE, (0,j) INSERT (seq_aligner.h:140-147)
+            const int src = j == 0 ? 3 : (i == 0 ? 2 : (int)ld_coherent_u8(par + (size_t)i * W + (j - i + md)));
+            const int u = __builtin_amdgcn_readfirstlane(src);
+            sink.put(u);
+            if (u == 1) { --i; --j; } else if (u == 2) --j; else --i;
+        }
+    } else {
+        const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
+        const int w1 = bv_first_w(md);
+        int best = 0, bestj = 0;
+        bool wide = false;
+        if (bv_trace_words(NB1, m, n, w1) > cap_words || w1 > bv_max_w(NB1)) { o.rc = -2; return; }   // host sizes both
+        int fr = bitvec_pass<NB1, true>(rowsF, m, colsF, n, w1, R, best, bestj, scratch, swap);
+        if (fr) { o.fail_row = fr; return; }
+        if (w1 < md && best > w1) {                         // goal row not certified: the reference band, in place
+            if (bv_trace_words(NB2, m, n, md) > cap_words || md > bv_max_w(NB2)) { o.rc = -2; return; }
+            wide = true;
+            fr = bitvec_pass<NB2, true>(rowsF, m, colsF, n, md, R, best, bestj, scratch, swap);
+            if (fr) { o.fail_row = fr; return; }           // cannot happen: the verdicts of the narrow pass were exact
+        }
+        o.cost = best;
+        o.matlen_a = swap ? bestj : m;
+        o.matlen_b = swap ? m : bestj;
+        o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114
+        if (o.rc < 0) return;
+        wave_mem_fence();                                    // the walk reads what other lanes stored
+        int ri = m, cj = bestj;
+        if (wide) bv_trace_walk<NB2>(scratch, ri, cj, swap, sink);
+        else bv_trace_walk<NB1>(scratch, ri, cj, swap, sink);
+        // border cells: the array's row 0 is the reference's i = 0 (INSERT) unless the roles are swapped
+        for (; ri > 0; --ri) sink.put(swap ? 2 : 3);
+        for (; cj > 0; --cj) sink.put(swap ? 3 : 2);
+    }
+    sink.flush();
+    wave_mem_fence();
+    const int k = sink.k;
+    for (int x = lane; x < k; x += PBA_WAVE)
+        if ((uint64_t)x < ops_cap) ops_out[x] = (uint8_t)ld_coherent_u8(tmp + (k - 1 - x));
+    nedit = k;
+}
+
+#endif

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "align_bitvec.h"
+#include "align_bvtrace.h"
 #include "align_rowsweep.h"
 #include "dev_common.h"
 #include "pba.h"
@@ -225,6 +226,33 @@ k_align_bytes_trace(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b
     AlnOut o;
     align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o, par);
     store_result(out, o);
+}
+
+// ---- traceback on the bit-vector array (align_bvtrace.h): persistent wavefronts, each with its own scratch area
+// of wave_words u32 (cap_words of parent bits, then the goal-first ops of the pair in flight)
+template <int NB1, int NB2>
+__global__ void __launch_bounds__(PBA_WAVE * 4, 2)
+k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n, AlignCfg cfg, pba_result *out,
+              uint32_t *scratch, uint64_t wave_words, uint64_t cap_words, uint8_t *ops, const uint64_t *ops_off,
+              int32_t *nedit, uint32_t *queue) {
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
+    uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    uint32_t *mine = scratch + ((uint64_t)blockIdx.x * 4 + wave) * wave_words;
+    for (;;) {
+        const uint32_t q = next_slot(queue);
+        if (q >= n) break;
+        const pba_pair pr = pairs[q];
+        PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
+        PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+        AlnOut o;
+        int ne = 0;
+        const uint64_t o0 = ops_off[q], o1 = ops_off[q + 1];
+        align_bitvec_trace<NB1, NB2>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap,
+                                     mine, cap_words, (uint8_t *)(mine + cap_words), ops + o0, o1 - o0, o, ne);
+        store_result(out + q, o);
+        if ((threadIdx.x & (PBA_WAVE - 1)) == 0) nedit[q] = ne;
+    }
 }
 
 // find_path (seq_aligner.h:214-233) walked iteratively from the goal cell; one thread per pair
@@ -1116,15 +1144,31 @@ int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int la, const c
     return PBA_OK;
 }
 
+// scratch the traced bit-vector pass of one pair needs (u32 words), both passes considered
+static uint64_t trace_words_of(int la, int lb, double R, int n1, int n2) {
+    const int md = max_dst_of(la, lb, R);
+    const int len_a = lb >= la ? la : std::min(la, lb + md), len_b = lb >= la ? std::min(lb, la + md) : lb;
+    const int m = std::min(len_a, len_b), n = std::max(len_a, len_b);
+    if (m <= 10) return (((uint64_t)len_a + 1) * (2ull * md + 1) + 3) / 4;       // the row sweep's corner: byte codes
+    return std::max(bv_trace_words(n1, m, n, bv_first_w(md)), bv_trace_words(n2, m, n, md));
+}
+
+#define PBA_TRACE_CASE(N1, N2)                                                                                       \
+    hipLaunchKernelGGL((k_trace_pairs<N1, N2>), dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(),    \
+                       B->dev(), d_pairs.as<pba_pair>(), (uint32_t)n, pl.cfg, d_out.as<pba_result>(),                \
+                       d_par.as<uint32_t>(), wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(),      \
+                       d_ne.as<int32_t>(), ctx->d_queue)
+
 int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
-                          int maxn, int maxm, pba_result *out, uint8_t *ops, const uint64_t *ops_off, int32_t *nedit) {
+                          int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
+                          int32_t *nedit) {
     if (!ctx || !A || !B || (!pairs && n) || (!out && n) || (!ops_off && n) || (!nedit && n)) return PBA_E_INVALID;
     if (n == 0) return PBA_OK;
     if (n > 0x7FFFFFFFull) PBA_FAIL(PBA_E_INVALID, "too many pairs in one batch");
     if (A->non_acgt || B->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "a sequence set holds bytes outside ACGT: use pba_align_text_trace");
     HIPCHK(hipSetDevice(ctx->device));
     int mdmax = 1;
-    std::vector<uint64_t> par_off(n + 1, 0);
+    uint64_t ops_max = 0;
     for (size_t q = 0; q < n; ++q) {
         const pba_pair &p = pairs[q];
         if (!pair_ok(A, p.a_seq, p.a_pos, p.a_len, p.flags & PBA_A_BACKWARD) ||
@@ -1132,42 +1176,77 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
             PBA_FAIL(PBA_E_INVALID, "pair outside its sequence (or longer than the engine limit)");
         if (ops_off[q + 1] < ops_off[q] || ops_off[q + 1] - ops_off[q] < (uint64_t)p.a_len + p.b_len)
             PBA_FAIL(PBA_E_INVALID, "ops_off must leave a_len + b_len slots per pair");
-        if (R > 0.0 && R < 1.0) {
-            mdmax = std::max(mdmax, max_dst_of(p.a_len, p.b_len, R));
-            par_off[q + 1] = par_off[q] + ((par_bytes_of(p.a_len, p.b_len, R) + 15) & ~15ull);
-        }
+        if (R > 0.0 && R < 1.0) mdmax = std::max(mdmax, max_dst_of(p.a_len, p.b_len, R));
+        ops_max = std::max(ops_max, (uint64_t)p.a_len + p.b_len);
     }
     Plan pl;
-    int st = make_plan(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, mdmax, &pl);
+    int st = make_plan(ctx, R, maxn, maxm, kernel, mdmax, &pl);
     if (st != PBA_OK) return st;
-    if (par_off[n] > kTraceBudget) PBA_FAIL(PBA_E_NOMEM, "parent codes of this batch exceed the traceback budget: split it");
     const uint64_t ops_total = ops_off[n] - ops_off[0];
     DevBuf d_pairs, d_out, d_par, d_poff, d_ops, d_ooff, d_ne;
     HIPCHK(hipMalloc(&d_pairs.p, sizeof(pba_pair) * n));
     HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
-    HIPCHK(hipMalloc(&d_par.p, par_off[n] + 16));
-    HIPCHK(hipMalloc(&d_poff.p, sizeof(uint64_t) * (n + 1)));
     HIPCHK(hipMalloc(&d_ops.p, ops_total + 16));
     HIPCHK(hipMalloc(&d_ooff.p, sizeof(uint64_t) * (n + 1)));
     HIPCHK(hipMalloc(&d_ne.p, sizeof(int32_t) * n));
     std::vector<uint64_t> rel(n + 1);
     for (size_t q = 0; q <= n; ++q) rel[q] = ops_off[q] - ops_off[0];
     HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_poff.p, par_off.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_ooff.p, rel.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_align_pairs_trace, dim3((uint32_t)n), dim3(PBA_WAVE), pl.lds, ctx->stream, A->dev(), B->dev(),
-                       d_pairs.as<pba_pair>(), (uint32_t)n, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>(),
-                       d_poff.as<uint64_t>());
-    hipLaunchKernelGGL(k_trace_walk, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out.as<pba_result>(),
-                       d_par.as<uint8_t>(), d_poff.as<uint64_t>(), d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(),
-                       d_ne.as<int32_t>(), (uint32_t)n);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::min<uint64_t>(kTraceBudget, (uint64_t)(free_b / 10) * 8);
+    (void)hipEventRecord(ctx->ev[2], ctx->stream);
+    if (pl.nb1 == 0) {
+        // row sweep: one parent byte per band cell, every pair's codes resident at once
+        std::vector<uint64_t> par_off(n + 1, 0);
+        for (size_t q = 0; q < n; ++q)
+            par_off[q + 1] = par_off[q] + ((par_bytes_of(pairs[q].a_len, pairs[q].b_len, R) + 15) & ~15ull);
+        if (par_off[n] > budget) PBA_FAIL(PBA_E_NOMEM, "parent codes of this batch exceed the traceback budget: split it");
+        HIPCHK(hipMalloc(&d_par.p, par_off[n] + 16));
+        HIPCHK(hipMalloc(&d_poff.p, sizeof(uint64_t) * (n + 1)));
+        HIPCHK(hipMemcpyAsync(d_poff.p, par_off.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_align_pairs_trace, dim3((uint32_t)n), dim3(PBA_WAVE), pl.lds, ctx->stream, A->dev(), B->dev(),
+                           d_pairs.as<pba_pair>(), (uint32_t)n, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>(),
+                           d_poff.as<uint64_t>());
+        hipLaunchKernelGGL(k_trace_walk, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out.as<pba_result>(),
+                           d_par.as<uint8_t>(), d_poff.as<uint64_t>(), d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(),
+                           d_ne.as<int32_t>(), (uint32_t)n);
+        ctx->prof.nb_first = 0;
+    } else {
+        // bit-vector array: 2 bits per processed cell in a per-wavefront scratch area, walked by the same wavefront
+        static const int kN2[9] = {0, 2, 4, 6, 8, 0, 8, 0, 8};      // instantiated (NB1, NB2) combinations
+        const int n1 = pl.nb1, n2 = kN2[pl.nb1];
+        uint64_t cap_words = 128;
+        for (size_t q = 0; q < n; ++q) cap_words = std::max(cap_words, trace_words_of(pairs[q].a_len, pairs[q].b_len, R, n1, n2));
+        cap_words = (cap_words + 63) & ~63ull;
+        const uint64_t wave_words = cap_words + ((ops_max + 64 + 255) & ~255ull) / 4;
+        uint32_t grid = persistent_grid(ctx, (uint32_t)n, 4, pl.lds);
+        grid = (uint32_t)std::min<uint64_t>(grid, budget / (wave_words * 4 * 4));
+        if (grid == 0) PBA_FAIL(PBA_E_NOMEM, "one wavefront's parent bits exceed the traceback budget");
+        HIPCHK(hipMalloc(&d_par.p, (size_t)grid * 4 * wave_words * 4));
+        HIPCHK(hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
+        switch (n1) {
+            case 1: PBA_TRACE_CASE(1, 2); break;
+            case 2: PBA_TRACE_CASE(2, 4); break;
+            case 3: PBA_TRACE_CASE(3, 6); break;
+            case 4: PBA_TRACE_CASE(4, 8); break;
+            case 6: PBA_TRACE_CASE(6, 8); break;
+            default: PBA_TRACE_CASE(8, 8); break;
+        }
+        ctx->prof.nb_first = (uint32_t)n1;
+    }
+    (void)hipEventRecord(ctx->ev[3], ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(nedit, d_ne.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     if (ops_total) HIPCHK(hipMemcpyAsync(ops + ops_off[0], d_ops.p, ops_total, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->prof.n_redo = 0;
+    prof_finish(ctx);
     return PBA_OK;
 }
+#undef PBA_TRACE_CASE
 
 // ---------------------------------------------------------------------------------------------
 // host API: drivers

@@ -239,7 +239,8 @@ class Context:
                                                  R, maxn, maxm, _ptr(out), _ptr(ops), cap, C.byref(ne)), "align_text_trace")
         return out[0], ops[:ne.value].copy()
 
-    def align_batch_trace(self, A: "SeqSet", B: "SeqSet", pairs: np.ndarray, R: float, maxn: int = 0, maxm: int = 0):
+    def align_batch_trace(self, A: "SeqSet", B: "SeqSet", pairs: np.ndarray, R: float, maxn: int = 0, maxm: int = 0,
+                          kernel: int = PBA_KERNEL_AUTO):
         """Returns (results, list of ops arrays)."""
         pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
         out = np.zeros(pairs.size, RESULT_DTYPE)
@@ -247,7 +248,7 @@ class Context:
         off[1:] = np.cumsum(pairs["a_len"].astype(np.int64) + pairs["b_len"].astype(np.int64)).astype(np.uint64)
         ops = np.zeros(int(off[-1]) + 1, np.uint8)
         ne = np.zeros(max(pairs.size, 1), np.int32)
-        self.check(self.lib.pba_align_batch_trace(self.h, A.h, B.h, _ptr(pairs), pairs.size, R, maxn, maxm, _ptr(out), _ptr(ops),
+        self.check(self.lib.pba_align_batch_trace(self.h, A.h, B.h, _ptr(pairs), pairs.size, R, maxn, maxm, kernel, _ptr(out), _ptr(ops),
                                                   _ptr(off), _ptr(ne)), "align_batch_trace")
         return out, [ops[int(off[q]):int(off[q]) + int(ne[q])].copy() for q in range(pairs.size)]
 
