@@ -1097,7 +1097,7 @@ int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b
 }
 
 // ---- traceback
-static const uint64_t kTraceBudget = 48ull << 30;      // parent codes resident for one call
+static const uint64_t kTraceBudget = 96ull << 30;      // parent codes / bits resident for one call (and at most 80 % of free HBM)
 
 static uint64_t par_bytes_of(int la, int lb, double R) {           // (len_a + 1) * (2*max_dst + 1), seq_aligner.h:94-102
     const int md = max_dst_of(la, lb, R);
