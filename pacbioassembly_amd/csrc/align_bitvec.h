@@ -24,10 +24,16 @@
 // per row" and the row above the window as "+1 per column", which are real (if expensive) paths,
 // so everything computed is an upper bound W >= U that equals U whenever U's optimal path stays
 // within |i-j| <= w.
-// With w >= max_dst/2 every diagonal verdict is exact (an out-of-window path costs >= 2w+2 >
-// floor(i*R)); the goal row is exact when its minimum is <= w (any unseen path costs >= w+1);
-// otherwise the pair is re-run with w = max_dst, the reference's own band, where the two
-// bullets above apply directly.  Results are bit-identical to the reference in all cases.
+// The window is asymmetric: wl columns left of the diagonal, w right of it.  Goal cells lie right
+// of the diagonal (j >= m), so a path that leaves on the left must come back: it costs >= 2*wl+2,
+// one that leaves on the right >= w+1.  Hence:
+//   * a PASSING diagonal verdict is always exact (W >= U);  a FAILING one at row i is exact when
+//     floor(i*R) < 2*wl+2 (no unseen path back to the diagonal is cheap enough to change it);
+//   * the goal row is exact when its minimum is <= min(w, 2*wl+1).
+// Anything else answers "uncertified" and the pair is re-run with wl = w = max_dst, the reference's
+// own band, where the two bullets above apply directly.  Results are bit-identical to the reference
+// in all cases.  First pass: w = 9/16 max_dst, wl = w/2: 25 % fewer cells than a symmetric window and,
+// more to the point, narrow enough for one block less per lane at BASELINE sizes.
 #ifndef PBA_ALIGN_BITVEC_H
 #define PBA_ALIGN_BITVEC_H
 
@@ -40,14 +46,15 @@
 #define PBA_BV_BAND_NUM 9      // first-pass half width = max(max_dst/2, 9/16 * max_dst) + 1
 #define PBA_BV_BAND_DEN 16
 
-// largest half-width a superblock of NB blocks supports: lane s must be done with superblock s
-// before superblock s+64 starts (2w <= 63*32*NB + 64)
-__device__ __host__ inline int bv_max_w(int nb) { return 1008 * nb + 32; }
-__device__ __host__ inline int bv_nb_for(int w) {
-    const int need = (w - 32 + 1007) / 1008;
+// widest window (wl + w) a superblock of NB blocks supports: lane s must be done with superblock s
+// before superblock s+64 starts (wl + w <= 63*32*NB + 64)
+__device__ __host__ inline int bv_max_span(int nb) { return 2016 * nb + 64; }
+__device__ __host__ inline int bv_nb_for_span(int span) {
+    const int need = (span - 64 + 2015) / 2016;
     const int nb = need < 1 ? 1 : need;
     return nb <= 4 ? nb : (nb <= 6 ? 6 : (nb <= 8 ? 8 : 0));   // instantiated: 1,2,3,4,6,8; 0 = too wide
 }
+__device__ __host__ inline int bv_nb_for(int w) { return bv_nb_for_span(2 * w); }   // symmetric window
 
 // 64 bits of an accessor's 2-bit stream starting at base index `idx` (may be unaligned / slightly out of
 // range: sequence sets carry 1 KB of readable slack on both sides): bit 63:62 = base idx, ..., bit 1:0 = base idx+31
@@ -110,7 +117,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
     return d;
 }
 
-// One sweep with half-width w.  Returns 0 when all diagonal checks pass (then best / bestj hold the
+// One sweep over the window [i - wleft, i + w].  Returns 0 when all diagonal checks pass (then best / bestj hold the
 // goal-row minimum and its column), else the first failing row.
 //
 // Instruction budget (measured on MI355X, tools/ubench_ops: and/or/xor/add/sub/not/bitop3/ashr issue every
@@ -127,13 +134,13 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 //            parent is not diagonal (INSERT is tried first and wins the tie, seq_aligner.h:167-173)
 // at tr[((t-1) * NB + nb) * 128 + word * 64 + lane]: 256 contiguous bytes per store instruction.
 template <int NB, bool TRACE = false>
-__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int w,
+__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int wleft, int w,
                                            double R, int &best_out, int &bestj_out, uint32_t *tr = nullptr,
                                            bool swap_roles = false) {
     constexpr int RB = 32 * NB;                 // rows per superblock
     const int lane = threadIdx.x & (PBA_WAVE - 1);
     m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);   // wave-uniform by construction
-    w = __builtin_amdgcn_readfirstlane(w);
+    w = __builtin_amdgcn_readfirstlane(w); wleft = __builtin_amdgcn_readfirstlane(wleft);
     const int S = (m + RB - 1) / RB;            // superblocks
     const int s_m = S - 1;                      // superblock, block and bit of row m
     const int nb_m = ((m - 1) - s_m * RB) >> 5, r_m = (m - 1) & 31;
@@ -155,7 +162,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         const int base_row = s_cur * RB;
         opened = false;
         if (s_cur < S) {
-            const int lo = max(1, base_row + 1 - w), hi = min(n, base_row + RB + w);
+            const int lo = max(1, base_row + 1 - wleft), hi = min(n, base_row + RB + w);
             t_evt = lo + s_cur;
             t_close1 = hi + s_cur + 1;
             t_hin_end = s_cur > 0 ? base_row + w + s_cur : INT_MIN;
@@ -269,14 +276,18 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     (void)tr_lane;
 #define PBA_BV_TRP() (tr_lane + (size_t)(t - 1) * (NB * 128))
     // ------------------------------------------------------------------ phase 1: down to cell (m,m)
+    // The step loop is cut into chunks of 32 steps (one pair of text planes): the scalar unit is shared by the CU's
+    // four SIMDs, so every SALU instruction of the step costs four issue cycles -- the inner loop carries nothing
+    // but its counter.  Everything in it is wave-uniform and stays in SGPRs.
     bool failed = false;
-    for (int t = 1; t <= t1; ++t) {              // t is wave-uniform and not live out of the loop: stays in an SGPR
+    for (int tbv = 1; tbv <= t1; tbv += 32) {
+        const int tb = __builtin_amdgcn_readfirstlane(tbv);   // (the early exit below makes the compiler treat tbv as divergent)
+        load_text(tb);                           // next text planes; poll for failure
+        if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; break; }
+        const int kend = min(32, t1 - tb + 1);
+        for (int k = 0; k < kend; ++k) {
+        const int t = tb + k;
         PBA_BV_RARE();
-        const int k = (t - 1) & 31;
-        if (k == 0) {                            // wave-uniform, every 32 steps: next text planes, poll for failure
-            load_text(t);
-            if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; break; }
-        }
         const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
 #pragma unroll
@@ -295,6 +306,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         }
         hp_last = hp; hn_last = hn;
         dmw = (dmw << 1) | (dmw >> 31);
+        }
     }
     int t = t1 + 1;
     if (!failed) {                               // segments that ended in the last step (the one holding row m does)
@@ -313,10 +325,13 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
 
     // ------------------------------------------------------------------ phase 2: goal row right of the diagonal
     const bool owner = s_cur == s_m;             // the lane holding row m
-    for (t = t1 + 1; t <= t_end; ++t) {
+    for (int tb = t1 + 1; tb <= t_end;) {
+        const int k0 = (tb - 1) & 31;            // phase 2 starts inside a chunk whose planes are already loaded
+        if (k0 == 0) load_text(tb);
+        const int kend = min(32, k0 + (t_end - tb + 1));
+        for (int k = k0; k < kend; ++k) {
+        const int t = tb - k0 + k;
         PBA_BV_RARE();
-        const int k = (t - 1) & 31;
-        if (k == 0) load_text(t);
         const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
         uint32_t ph_m = 0, mh_m = 0;
@@ -337,6 +352,8 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             score += (int)((ph_m >> r_m) & 1u) - (int)((mh_m >> r_m) & 1u);
             if (score < best) { best = score; bestj = t - s_m; }
         }
+        }
+        tb += kend - k0;
     }
 #undef PBA_BV_BLOCK
 #undef PBA_BV_TRP
@@ -353,11 +370,22 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
 
 // true when the bit-vector kernel can take a pair with this max_dst (else: row sweep)
 __device__ __host__ inline bool bitvec_supports(int max_dst) { return bv_nb_for(max_dst) != 0; }
-// first-pass half width for a given max_dst
+// first-pass window for a given max_dst: w columns right of the diagonal, wl left of it
 __device__ __host__ inline int bv_first_w(int md) {
     const int w = (md / 2 > (int)((long long)md * PBA_BV_BAND_NUM / PBA_BV_BAND_DEN)
                        ? md / 2 : (int)((long long)md * PBA_BV_BAND_NUM / PBA_BV_BAND_DEN)) + 1;
     return w > md ? md : w;
+}
+__device__ __host__ inline int bv_first_wl(int md) {
+    const int wl = bv_first_w(md) / 2 + 1;
+    return wl > md ? md : wl;
+}
+// the verdicts of a sweep over [i - wl, i + w] (header comment): a failure at row fr / a goal minimum `best`
+__device__ __forceinline__ bool bv_fail_certified(int fr, double R, int wl, int md) {
+    return wl >= md || (double)fr * R < (double)(2 * wl + 2);
+}
+__device__ __forceinline__ bool bv_goal_certified(int best, int wl, int w, int md) {
+    return (w >= md && wl >= md) || (best <= w && best <= 2 * wl + 1);
 }
 
 #define PBA_RC_UNCERTIFIED (-3)   // narrow pass could not certify the goal row: re-run with full_band
@@ -380,13 +408,16 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
         align_rowsweep(fa, la, fb, lb, R, maxn, maxm, lds, lds_cells, o);
         return;
     }
-    const int w = full_band ? md : bv_first_w(md);
-    if (w > bv_max_w(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
+    const int w = full_band ? md : bv_first_w(md), wl = full_band ? md : bv_first_wl(md);
+    if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
     const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
     int best = 0, bestj = 0;
-    const int fr = bitvec_pass<NB>(rowsF, m, colsF, n, w, R, best, bestj);
-    if (fr) { o.fail_row = fr; return; }
-    if (w < md && best > w) { o.rc = PBA_RC_UNCERTIFIED; return; }     // header comment: goal row not certified
+    const int fr = bitvec_pass<NB>(rowsF, m, colsF, n, wl, w, R, best, bestj);
+    if (fr) {
+        if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
+        return;
+    }
+    if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return; }   // header comment
     o.cost = best;
     o.matlen_a = swap ? bestj : m;
     o.matlen_b = swap ? m : bestj;

@@ -128,17 +128,17 @@ __device__ __forceinline__ void align_bitvec_trace(const PackedFetch &fa, int la
         }
     } else {
         const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
-        const int w1 = bv_first_w(md);
+        const int w1 = bv_first_w(md), wl1 = bv_first_wl(md);
         int best = 0, bestj = 0;
         bool wide = false;
-        if (bv_trace_words(NB1, m, n, w1) > cap_words || w1 > bv_max_w(NB1)) { o.rc = -2; return; }   // host sizes both
-        int fr = bitvec_pass<NB1, true>(rowsF, m, colsF, n, w1, R, best, bestj, scratch, swap);
-        if (fr) { o.fail_row = fr; return; }
-        if (w1 < md && best > w1) {                         // goal row not certified: the reference band, in place
-            if (bv_trace_words(NB2, m, n, md) > cap_words || md > bv_max_w(NB2)) { o.rc = -2; return; }
+        if (bv_trace_words(NB1, m, n, w1) > cap_words || wl1 + w1 > bv_max_span(NB1)) { o.rc = -2; return; }   // host sizes both
+        int fr = bitvec_pass<NB1, true>(rowsF, m, colsF, n, wl1, w1, R, best, bestj, scratch, swap);
+        if (fr && bv_fail_certified(fr, R, wl1, md)) { o.fail_row = fr; return; }
+        if (fr || !bv_goal_certified(best, wl1, w1, md)) {  // not certified: the reference band, in place
+            if (bv_trace_words(NB2, m, n, md) > cap_words || 2 * md > bv_max_span(NB2)) { o.rc = -2; return; }
             wide = true;
-            fr = bitvec_pass<NB2, true>(rowsF, m, colsF, n, md, R, best, bestj, scratch, swap);
-            if (fr) { o.fail_row = fr; return; }           // cannot happen: the verdicts of the narrow pass were exact
+            fr = bitvec_pass<NB2, true>(rowsF, m, colsF, n, md, md, R, best, bestj, scratch, swap);
+            if (fr) { o.fail_row = fr; return; }
         }
         o.cost = best;
         o.matlen_a = swap ? bestj : m;

@@ -980,7 +980,7 @@ static int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int
     pl->cfg.R = R; pl->cfg.maxn = maxn; pl->cfg.maxm = maxm; pl->cfg.full_band = 0;
     pl->cfg.row_cap = (int)(bytes / 2);
     pl->lds = (size_t)bytes;
-    pl->nb1 = bv ? bv_nb_for(bv_first_w(max_dst_max)) : 0;
+    pl->nb1 = bv ? bv_nb_for_span(bv_first_wl(max_dst_max) + bv_first_w(max_dst_max)) : 0;
     pl->nb2 = bv ? bv_nb_for(max_dst_max) : 0;
     return PBA_OK;
 }
@@ -1215,7 +1215,7 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
         ctx->prof.nb_first = 0;
     } else {
         // bit-vector array: 2 bits per processed cell in a per-wavefront scratch area, walked by the same wavefront
-        static const int kN2[9] = {0, 2, 4, 6, 8, 0, 8, 0, 8};      // instantiated (NB1, NB2) combinations
+        static const int kN2[9] = {0, 3, 6, 8, 8, 0, 8, 0, 8};      // instantiated (NB1, NB2) combinations: NB2 >= any nb2 that goes with NB1
         const int n1 = pl.nb1, n2 = kN2[pl.nb1];
         uint64_t cap_words = 128;
         for (size_t q = 0; q < n; ++q) cap_words = std::max(cap_words, trace_words_of(pairs[q].a_len, pairs[q].b_len, R, n1, n2));
@@ -1227,9 +1227,9 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
         HIPCHK(hipMalloc(&d_par.p, (size_t)grid * 4 * wave_words * 4));
         HIPCHK(hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
         switch (n1) {
-            case 1: PBA_TRACE_CASE(1, 2); break;
-            case 2: PBA_TRACE_CASE(2, 4); break;
-            case 3: PBA_TRACE_CASE(3, 6); break;
+            case 1: PBA_TRACE_CASE(1, 3); break;
+            case 2: PBA_TRACE_CASE(2, 6); break;
+            case 3: PBA_TRACE_CASE(3, 8); break;
             case 4: PBA_TRACE_CASE(4, 8); break;
             case 6: PBA_TRACE_CASE(6, 8); break;
             default: PBA_TRACE_CASE(8, 8); break;
@@ -1514,14 +1514,13 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
         case 0: PBA_OVL_CASE(0, 0); break;
         case 11: PBA_OVL_CASE(1, 1); break;
         case 12: PBA_OVL_CASE(1, 2); break;
-        case 22: PBA_OVL_CASE(2, 2); break;
+        case 13: PBA_OVL_CASE(1, 3); break;
         case 23: PBA_OVL_CASE(2, 3); break;
         case 24: PBA_OVL_CASE(2, 4); break;
-        case 34: PBA_OVL_CASE(3, 4); break;
+        case 26: PBA_OVL_CASE(2, 6); break;
         case 36: PBA_OVL_CASE(3, 6); break;
-        case 46: PBA_OVL_CASE(4, 6); break;
+        case 38: PBA_OVL_CASE(3, 8); break;
         case 48: PBA_OVL_CASE(4, 8); break;
-        case 68: PBA_OVL_CASE(6, 8); break;
         default: PBA_OVL_CASE(8, 8); break;      // any pair with nb1 <= 8 and nb2 <= 8 is valid (NB only needs to be large enough)
     }
     (void)hipEventRecord(ctx->ev[5], ctx->stream);
