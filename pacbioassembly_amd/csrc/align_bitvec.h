@@ -132,7 +132,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 //   word 1 = Ph (horizontal +1 entering the cell from the left), or the new Pv (vertical +1) when the rows are
 //            the reference's b (`swap_roles`): set = the reference's INSERT, clear = its DELETE, for cells whose
 //            parent is not diagonal (INSERT is tried first and wins the tie, seq_aligner.h:167-173)
-// at tr[((t-1) * NB + nb) * 128 + word * 64 + lane]: 256 contiguous bytes per store instruction.
+// at tr[((t-1) * NB + nb) * 128 + 2 * lane + word]: one 8-byte store per lane, 512 contiguous bytes per instruction.
 template <int NB, bool TRACE = false>
 __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int wleft, int w,
                                            double R, int &best_out, int &bestj_out, uint32_t *tr = nullptr,
@@ -156,11 +156,11 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     int t_diag0;       // step at which this lane's first row is on the diagonal
     int t_dstart;      // = t_diag0 until the diagonal has entered this lane's rows
     int t_seg;         // step at which the current 32-row diagonal segment of this lane is complete
-    bool opened = false;
+    uint32_t opened = 0;   // 0 / 1 in a VGPR (a bool would live in an SGPR pair and be re-merged with exec every step)
 
     auto open_superblock = [&]() {              // s_cur names the superblock this lane now owns
         const int base_row = s_cur * RB;
-        opened = false;
+        opened = 0;
         if (s_cur < S) {
             const int lo = max(1, base_row + 1 - wleft), hi = min(n, base_row + RB + w);
             t_evt = lo + s_cur;
@@ -228,7 +228,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             if (opened) { s_cur += PBA_WAVE; open_superblock(); }                     \
             if (t == t_evt) {                                                         \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; } \
-                opened = true;                                                        \
+                opened = 1;                                                           \
                 t_evt = t_close1;                                                     \
             }                                                                         \
             load_text(t - ((t - 1) & 31));                                            \
@@ -272,9 +272,9 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
 
     // TRACE: this lane's slot of step t, block 0, word 0.  Recomputed from t every step: a pointer carried through
     // the loop loses its increment on the text-refill path of the step loop (ROCm 7.2 clang, seen in the ISA)
-    uint32_t *const tr_lane = tr + lane;
+    uint2 *const tr_lane = (uint2 *)tr + lane;
     (void)tr_lane;
-#define PBA_BV_TRP() (tr_lane + (size_t)(t - 1) * (NB * 128))
+#define PBA_BV_TRP() (tr_lane + (size_t)(t - 1) * (NB * 64))
     // ------------------------------------------------------------------ phase 1: down to cell (m,m)
     // The step loop is cut into chunks of 32 steps (one pair of text planes): the scalar unit is shared by the CU's
     // four SIMDs, so every SALU instruction of the step costs four issue cycles -- the inner loop carries nothing
@@ -295,11 +295,8 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             uint32_t d0, php, mhp, eq;
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
             (void)php; (void)mhp; (void)eq;
-            if constexpr (TRACE) {           // all 64 lanes store (256 contiguous bytes per instruction): masking the lanes
-                uint32_t *const trp = PBA_BV_TRP();   // outside their window was measured 1.5x SLOWER (partial lines)
-                trp[nb * 128] = eq | ~d0;
-                trp[nb * 128 + 64] = swap_roles ? Pv[nb] : php;
-            }
+            if constexpr (TRACE)             // all 64 lanes store (512 contiguous bytes per instruction): masking the lanes
+                PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);   // outside their window was measured 1.5x SLOWER
             // keep the diagonal cell's D0 bit (garbage while the diagonal is in another block: the word is
             // cleared when the diagonal enters)
             acc[nb] = or_of_and(acc[nb], d0, dmw);
@@ -341,11 +338,8 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
             (void)d0; (void)eq;
             if (nb == nb_m) { ph_m = php; mh_m = mhp; }
-            if constexpr (TRACE) {           // all 64 lanes store (256 contiguous bytes per instruction): masking the lanes
-                uint32_t *const trp = PBA_BV_TRP();   // outside their window was measured 1.5x SLOWER (partial lines)
-                trp[nb * 128] = eq | ~d0;
-                trp[nb * 128 + 64] = swap_roles ? Pv[nb] : php;
-            }
+            if constexpr (TRACE)             // all 64 lanes store (512 contiguous bytes per instruction): masking the lanes
+                PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);   // outside their window was measured 1.5x SLOWER
         }
         hp_last = hp; hn_last = hn;
         if (owner) {                             // D(m,j) = D(m,j-1) + horizontal delta at row m (seq_aligner.h:202-211)

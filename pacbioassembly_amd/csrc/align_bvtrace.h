@@ -3,7 +3,7 @@
 //
 // The forward pass is bitvec_pass<NB, TRACE = true> (align_bitvec.h): the same sweep as the score-only kernel,
 // which also streams two words per (step, block, lane) into a per-wavefront scratch area -- 2 bits per DP
-// cell, 256 contiguous bytes per store instruction.  The parent of a cell, decided by the reference with strict
+// cell, 512 contiguous bytes per store instruction.  The parent of a cell, decided by the reference with strict
 // comparisons in the order MATCH, INSERT, DELETE (seq_aligner.h:164-173), is a function of the cell's delta bits:
 //   * Eq                     -> diagonal (cost D(i-1,j-1) is a lower bound of the cell, MATCH is tried first)
 //   * !Eq, D0 = 0            -> diagonal (a substitution; the cell is D(i-1,j-1)+1 and nothing is strictly cheaper)
@@ -37,8 +37,9 @@ __device__ __host__ inline uint64_t bv_trace_words(int nb, int m, int n, int w) 
 // by the CU), so plain loads behind a workgroup-scope fence (the stores have completed) are coherent.  Agent-scope
 // (sc1) loads are not the tool here: they are served past this XCD's L2, which still holds the lines dirty.
 __device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ uint2 ld_coherent2(const uint32_t *p) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 __device__ __forceinline__ uint32_t ld_coherent_u8(const uint8_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -73,9 +74,9 @@ __device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &
         const int tt = cj + s - lane;                      // lane d looks at the step d before the cell's
         uint32_t wm = 0, wh = 0;
         if (tt >= 1) {
-            const uint32_t *p = tr + ((size_t)(tt - 1) * NB + nb) * 128 + ln;
-            wm = ld_coherent(p);
-            wh = ld_coherent(p + 64);
+            const uint2 v = ld_coherent2(tr + ((size_t)(tt - 1) * NB + nb) * 128 + 2 * ln);
+            wm = v.x;
+            wh = v.y;
         }
         int d = 0;
         do {
@@ -93,15 +94,16 @@ __device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &
     }
 }
 
-// One pair with its edit script.  NB1: blocks per lane of the narrow first pass, NB2 of the reference-band
-// re-run taken in place when the narrow pass cannot certify the goal row.
+// One pair with its edit script.  full_band = false sweeps the narrow first-pass window and answers
+// PBA_RC_UNCERTIFIED (no script) when its verdict cannot be certified; the host re-launches those pairs with
+// full_band = true (the reference band), like the score-only kernels do.
 // scratch: cap_words u32 of this wavefront's own; tmp: >= la + lb + 64 bytes of this wavefront's own.
 // ops_out receives min(nedit, ops_cap) ops in the reference's order (origin first); nedit = 0 unless o.rc >= 0.
-template <int NB1, int NB2>
+template <int NB>
 __device__ __forceinline__ void align_bitvec_trace(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
-                                                   int maxn, int maxm, uint16_t *lds, int lds_cells, uint32_t *scratch,
-                                                   uint64_t cap_words, uint8_t *tmp, uint8_t *ops_out, uint64_t ops_cap,
-                                                   AlnOut &o, int &nedit) {
+                                                   int maxn, int maxm, bool full_band, uint16_t *lds, int lds_cells,
+                                                   uint32_t *scratch, uint64_t cap_words, uint8_t *tmp, uint8_t *ops_out,
+                                                   uint64_t ops_cap, AlnOut &o, int &nedit) {
     const int lane = threadIdx.x & (PBA_WAVE - 1);
     nedit = 0;
     aln_params(la, lb, R, o);
@@ -128,27 +130,23 @@ __device__ __forceinline__ void align_bitvec_trace(const PackedFetch &fa, int la
         }
     } else {
         const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
-        const int w1 = bv_first_w(md), wl1 = bv_first_wl(md);
+        const int w = full_band ? md : bv_first_w(md), wl = full_band ? md : bv_first_wl(md);
         int best = 0, bestj = 0;
-        bool wide = false;
-        if (bv_trace_words(NB1, m, n, w1) > cap_words || wl1 + w1 > bv_max_span(NB1)) { o.rc = -2; return; }   // host sizes both
-        int fr = bitvec_pass<NB1, true>(rowsF, m, colsF, n, wl1, w1, R, best, bestj, scratch, swap);
-        if (fr && bv_fail_certified(fr, R, wl1, md)) { o.fail_row = fr; return; }
-        if (fr || !bv_goal_certified(best, wl1, w1, md)) {  // not certified: the reference band, in place
-            if (bv_trace_words(NB2, m, n, md) > cap_words || 2 * md > bv_max_span(NB2)) { o.rc = -2; return; }
-            wide = true;
-            fr = bitvec_pass<NB2, true>(rowsF, m, colsF, n, md, md, R, best, bestj, scratch, swap);
-            if (fr) { o.fail_row = fr; return; }
+        if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes both
+        const int fr = bitvec_pass<NB, true>(rowsF, m, colsF, n, wl, w, R, best, bestj, scratch, swap);
+        if (fr) {
+            if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
+            return;
         }
+        if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return; }
         o.cost = best;
         o.matlen_a = swap ? bestj : m;
         o.matlen_b = swap ? m : bestj;
         o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114
         if (o.rc < 0) return;
-        wave_mem_fence();                                    // the walk reads what other lanes stored
+        wave_mem_fence();                                   // the walk reads what other lanes stored
         int ri = m, cj = bestj;
-        if (wide) bv_trace_walk<NB2>(scratch, ri, cj, swap, sink);
-        else bv_trace_walk<NB1>(scratch, ri, cj, swap, sink);
+        bv_trace_walk<NB>(scratch, ri, cj, swap, sink);
         // border cells: the array's row 0 is the reference's i = 0 (INSERT) unless the roles are swapped
         for (; ri > 0; --ri) sink.put(swap ? 2 : 3);
         for (; cj > 0; --cj) sink.put(swap ? 3 : 2);

@@ -4,6 +4,7 @@
 // loudly (PBA_E_NODEVICE / PBA_E_HIP): there is no CPU path behind these entry points.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -229,27 +230,29 @@ k_align_bytes_trace(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b
 }
 
 // ---- traceback on the bit-vector array (align_bvtrace.h): persistent wavefronts, each with its own scratch area
-// of wave_words u32 (cap_words of parent bits, then the goal-first ops of the pair in flight)
-template <int NB1, int NB2>
-__global__ void __launch_bounds__(PBA_WAVE * 4, 2)
-k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n, AlignCfg cfg, pba_result *out,
-              uint32_t *scratch, uint64_t wave_words, uint64_t cap_words, uint8_t *ops, const uint64_t *ops_off,
-              int32_t *nedit, uint32_t *queue) {
+// of wave_words u32 (cap_words of parent bits, then the goal-first ops of the pair in flight).
+// ids (nullable): the subset of pairs to process (second, full-band launch)
+template <int NB>
+__global__ void __launch_bounds__(PBA_WAVE * 4, NB <= 4 ? 4 : 2)
+k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg,
+              pba_result *out, uint32_t *scratch, uint64_t wave_words, uint64_t cap_words, uint8_t *ops,
+              const uint64_t *ops_off, int32_t *nedit, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
     uint32_t *mine = scratch + ((uint64_t)blockIdx.x * 4 + wave) * wave_words;
     for (;;) {
-        const uint32_t q = next_slot(queue);
-        if (q >= n) break;
+        const uint32_t slot = next_slot(queue);
+        if (slot >= n) break;
+        const uint32_t q = ids ? ids[slot] : slot;
         const pba_pair pr = pairs[q];
         PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
         PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
         AlnOut o;
         int ne = 0;
         const uint64_t o0 = ops_off[q], o1 = ops_off[q + 1];
-        align_bitvec_trace<NB1, NB2>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap,
-                                     mine, cap_words, (uint8_t *)(mine + cap_words), ops + o0, o1 - o0, o, ne);
+        align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
+                               cfg.row_cap, mine, cap_words, (uint8_t *)(mine + cap_words), ops + o0, o1 - o0, o, ne);
         store_result(out + q, o);
         if ((threadIdx.x & (PBA_WAVE - 1)) == 0) nedit[q] = ne;
     }
@@ -1144,20 +1147,14 @@ int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int la, const c
     return PBA_OK;
 }
 
-// scratch the traced bit-vector pass of one pair needs (u32 words), both passes considered
-static uint64_t trace_words_of(int la, int lb, double R, int n1, int n2) {
+// scratch the traced bit-vector pass of one pair needs (u32 words): narrow first pass or reference band
+static uint64_t trace_words_of(int la, int lb, double R, int nb, bool full_band) {
     const int md = max_dst_of(la, lb, R);
     const int len_a = lb >= la ? la : std::min(la, lb + md), len_b = lb >= la ? std::min(lb, la + md) : lb;
     const int m = std::min(len_a, len_b), n = std::max(len_a, len_b);
     if (m <= 10) return (((uint64_t)len_a + 1) * (2ull * md + 1) + 3) / 4;       // the row sweep's corner: byte codes
-    return std::max(bv_trace_words(n1, m, n, bv_first_w(md)), bv_trace_words(n2, m, n, md));
+    return bv_trace_words(nb, m, n, full_band ? md : bv_first_w(md));
 }
-
-#define PBA_TRACE_CASE(N1, N2)                                                                                       \
-    hipLaunchKernelGGL((k_trace_pairs<N1, N2>), dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(),    \
-                       B->dev(), d_pairs.as<pba_pair>(), (uint32_t)n, pl.cfg, d_out.as<pba_result>(),                \
-                       d_par.as<uint32_t>(), wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(),      \
-                       d_ne.as<int32_t>(), ctx->d_queue)
 
 int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
                           int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
@@ -1195,7 +1192,9 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
     HIPCHK(hipMemcpyAsync(d_ooff.p, rel.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = std::min<uint64_t>(kTraceBudget, (uint64_t)(free_b / 10) * 8);
+    uint64_t budget = std::min<uint64_t>(kTraceBudget, (uint64_t)(free_b / 10) * 8);
+    if (const char *e = getenv("PBA_TRACE_BUDGET_GB"))       // tuning aid: HBM the parent bits / codes of one call may take
+        budget = std::min<uint64_t>((uint64_t)atoll(e) << 30, (uint64_t)(free_b / 10) * 9);
     (void)hipEventRecord(ctx->ev[2], ctx->stream);
     if (pl.nb1 == 0) {
         // row sweep: one parent byte per band cell, every pair's codes resident at once
@@ -1212,41 +1211,72 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
         hipLaunchKernelGGL(k_trace_walk, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_out.as<pba_result>(),
                            d_par.as<uint8_t>(), d_poff.as<uint64_t>(), d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(),
                            d_ne.as<int32_t>(), (uint32_t)n);
-        ctx->prof.nb_first = 0;
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        ctx->prof.nb_first = 0; ctx->prof.n_first = (uint32_t)n; ctx->prof.nb_redo = 0; ctx->prof.n_redo = 0;
+        ctx->prof.align_redo_ms = 0.f;
     } else {
-        // bit-vector array: 2 bits per processed cell in a per-wavefront scratch area, walked by the same wavefront
-        static const int kN2[9] = {0, 3, 6, 8, 8, 0, 8, 0, 8};      // instantiated (NB1, NB2) combinations: NB2 >= any nb2 that goes with NB1
-        const int n1 = pl.nb1, n2 = kN2[pl.nb1];
-        uint64_t cap_words = 128;
-        for (size_t q = 0; q < n; ++q) cap_words = std::max(cap_words, trace_words_of(pairs[q].a_len, pairs[q].b_len, R, n1, n2));
-        cap_words = (cap_words + 63) & ~63ull;
-        const uint64_t wave_words = cap_words + ((ops_max + 64 + 255) & ~255ull) / 4;
-        uint32_t grid = persistent_grid(ctx, (uint32_t)n, 4, pl.lds);
-        grid = (uint32_t)std::min<uint64_t>(grid, budget / (wave_words * 4 * 4));
-        if (grid == 0) PBA_FAIL(PBA_E_NOMEM, "one wavefront's parent bits exceed the traceback budget");
-        HIPCHK(hipMalloc(&d_par.p, (size_t)grid * 4 * wave_words * 4));
-        HIPCHK(hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
-        switch (n1) {
-            case 1: PBA_TRACE_CASE(1, 3); break;
-            case 2: PBA_TRACE_CASE(2, 6); break;
-            case 3: PBA_TRACE_CASE(3, 8); break;
-            case 4: PBA_TRACE_CASE(4, 8); break;
-            case 6: PBA_TRACE_CASE(6, 8); break;
-            default: PBA_TRACE_CASE(8, 8); break;
+        // bit-vector array: 2 bits per processed cell in a per-wavefront scratch area, walked by the same wavefront.
+        // First launch: every pair, narrow window, scratch sized for it (so more wavefronts fit the budget); second
+        // launch: the pairs that came back uncertified, reference band.
+        ctx->prof.nb_first = (uint32_t)pl.nb1; ctx->prof.n_first = (uint32_t)n;
+        ctx->prof.nb_redo = 0; ctx->prof.n_redo = 0; ctx->prof.align_redo_ms = 0.f;
+        std::vector<uint32_t> redo;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int nb = pass ? pl.nb2 : pl.nb1;
+            const uint32_t cnt = pass ? (uint32_t)redo.size() : (uint32_t)n;
+            uint64_t cap_words = 128;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const pba_pair &p = pairs[pass ? redo[k] : k];
+                cap_words = std::max(cap_words, trace_words_of(p.a_len, p.b_len, R, nb, pass != 0));
+            }
+            cap_words = (cap_words + 63) & ~63ull;
+            const uint64_t wave_words = cap_words + ((ops_max + 64 + 255) & ~255ull) / 4;
+            uint32_t grid = persistent_grid(ctx, cnt, 4, pl.lds);
+            grid = (uint32_t)std::min<uint64_t>(grid, budget / (wave_words * 4 * 4));
+            if (grid == 0) PBA_FAIL(PBA_E_NOMEM, "one wavefront's parent bits exceed the traceback budget");
+            DevBuf d_scr, d_ids;
+            HIPCHK(hipMalloc(&d_scr.p, (size_t)grid * 4 * wave_words * 4));
+            const uint32_t *ids = nullptr;
+            if (pass) {
+                HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * cnt));
+                HIPCHK(hipMemcpyAsync(d_ids.p, redo.data(), sizeof(uint32_t) * cnt, hipMemcpyHostToDevice, ctx->stream));
+                ids = d_ids.as<uint32_t>();
+                pl.cfg.full_band = 1;
+            }
+            HIPCHK(hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
+            (void)hipEventRecord(ctx->ev[pass ? 4 : 2], ctx->stream);
+#define K_TRACE(NBV)                                                                                                  \
+    hipLaunchKernelGGL(k_trace_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(),  \
+                       d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), d_scr.as<uint32_t>(),         \
+                       wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(), d_ne.as<int32_t>(),          \
+                       ctx->d_queue)
+            switch (nb) {
+                case 1: K_TRACE(1); break;
+                case 2: K_TRACE(2); break;
+                case 3: K_TRACE(3); break;
+                case 4: K_TRACE(4); break;
+                case 6: K_TRACE(6); break;
+                default: K_TRACE(8); break;
+            }
+#undef K_TRACE
+            (void)hipEventRecord(ctx->ev[pass ? 5 : 3], ctx->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));           // the scratch area is freed at the end of this pass
+            if (pass) { ctx->prof.nb_redo = (uint32_t)nb; ctx->prof.n_redo = cnt; break; }
+            for (size_t q = 0; q < n; ++q)
+                if (out[q].rc == PBA_RC_UNCERTIFIED) redo.push_back((uint32_t)q);
+            if (redo.empty()) break;
         }
-        ctx->prof.nb_first = (uint32_t)n1;
     }
-    (void)hipEventRecord(ctx->ev[3], ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(nedit, d_ne.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     if (ops_total) HIPCHK(hipMemcpyAsync(ops + ops_off[0], d_ops.p, ops_total, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->prof.n_redo = 0;
     prof_finish(ctx);
     return PBA_OK;
 }
-#undef PBA_TRACE_CASE
 
 // ---------------------------------------------------------------------------------------------
 // host API: drivers
