@@ -226,6 +226,36 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
                           const uint64_t *ops_off, int32_t *nedit);
 
 /* ------------------------------------------------------------------------ */
+/* Consensus voting and reference growth: the unlocked half of ref_seq      */
+/* (ref_seq.h:25-188 base_vote / vote_box, :207-242 ctor / append / prepend, */
+/* :317-362 evolve / elect).  One vote box per reference position, resident */
+/* in HBM; max_len plays MAX_SEQ_LEN (common.h:31): the object spans        */
+/* 3*max_len positions with its origin (`beg`) at max_len.                  */
+/* ------------------------------------------------------------------------ */
+typedef struct pba_cons pba_cons;
+/* ref_seq(const char*, int len, bool, int w) (ref_seq.h:218-225): every box starts as vote_box(text[i], weight) */
+int pba_cons_create(pba_ctx *ctx, const char *text, int len, int weight, int max_len, pba_cons **out);
+void pba_cons_destroy(pba_cons *c);
+/* extent[0..2] = pre - beg, post - beg, end - beg (ref_seq.h:364-367) */
+int pba_cons_extent(const pba_cons *c, int32_t *extent);
+/* ref_seq::append / prepend (ref_seq.h:227-242): seg holds the new characters in text order */
+int pba_cons_append(pba_ctx *ctx, pba_cons *c, const char *seg, int len);
+int pba_cons_prepend(pba_ctx *ctx, pba_cons *c, const char *seg, int len);
+/* ref_seq::elect + apply_edits (ref_seq.h:352-362, 25-41) for n edit scripts at once (votes commute): script q
+ * starts at reference position pos[q] (relative to beg, must be contained), runs forward (fwd[q] != 0) or
+ * backward, and is ops/vals[ops_off[q] .. +nedit[q]) with ops as pba_align_*_trace returns them and vals[k] =
+ * edits[k].val (the b element of a MATCH / INSERT, seq_aligner.h:218,224). */
+int pba_cons_elect(pba_ctx *ctx, pba_cons *c, uint32_t n, const int32_t *pos, const uint8_t *fwd, const uint8_t *ops,
+                   const char *vals, const uint64_t *ops_off, const int32_t *nedit);
+/* ref_seq::evolve (ref_seq.h:317-349): votes -> next reference; the boxes keep their counts, the new text
+ * (new_len characters, up to cap copied) starts at beg and pre = beg, post = end = beg + new_len. */
+int pba_cons_evolve(pba_ctx *ctx, pba_cons *c, char *text_out, int cap, int32_t *new_len);
+/* the boxes of [pre, post) in order: sel/sup 4 u16 each (A,C,G,T), tot; *n = their number (up to cap copied) */
+int pba_cons_dump(pba_ctx *ctx, const pba_cons *c, uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *n);
+/* the text of [pre, post) as ref_seq::get_accessor sees it */
+int pba_cons_text(pba_ctx *ctx, const pba_cons *c, char *out, int cap, int32_t *n);
+
+/* ------------------------------------------------------------------------ */
 /* Drivers: the reference's ordered first-success loops, run on the GPU.    */
 /* ------------------------------------------------------------------------ */
 typedef struct {

@@ -694,3 +694,159 @@ size_t orc_open_binary(const uint8_t *buf, size_t len, uint32_t min_excl, uint32
     if (n_total) *n_total = total;
     return kept;
 }
+
+
+/* =====================================================================================================
+ * consensus voting and reference growth (ref_seq.h), restated on flat arrays: box k of the list is text
+ * position pre + k.
+ * ===================================================================================================== */
+typedef struct { uint16_t sel[4], sup[4]; int32_t tot; } cbox;
+struct orc_cons {
+    int max_len;            /* MAX_SEQ_LEN */
+    char *txt;              /* 3 * max_len */
+    int beg, end, pre, post;
+    cbox *box;              /* list begin = box[0]; capacity 3 * max_len */
+    int nbox;
+};
+
+static cbox cbox_of(char ch, int n) {            /* vote_box(char c, int n): selection(c, n), total(1) -- ref_seq.h:118 */
+    cbox b;
+    memset(&b, 0, sizeof b);
+    b.sel[orc_c2i(ch)] = (uint16_t)(b.sel[orc_c2i(ch)] + n);
+    b.tot = 1;
+    return b;
+}
+static int cmax4(const uint16_t *v) {            /* base_vote::max_vote, ref_seq.h:88-91 */
+    int m = v[0];
+    if (v[1] > m) m = v[1];
+    if (v[2] > m) m = v[2];
+    if (v[3] > m) m = v[3];
+    return m;
+}
+static char cwinner(const uint16_t *v) {         /* base_vote::winner, ref_seq.h:96-100 */
+    const int mv = cmax4(v);
+    return mv == v[0] ? 'A' : (mv == v[1] ? 'C' : (mv == v[2] ? 'G' : 'T'));
+}
+
+orc_cons *orc_cons_new(const char *text, int len, int weight, int max_len) {
+    if (len > max_len) return NULL;
+    orc_cons *c = (orc_cons *)calloc(1, sizeof *c);
+    c->max_len = max_len;
+    c->txt = (char *)calloc((size_t)3 * max_len + 64, 1);
+    c->box = (cbox *)calloc((size_t)3 * max_len + 64, sizeof(cbox));
+    c->beg = c->pre = max_len;
+    c->end = c->post = c->beg + len;
+    memcpy(c->txt + c->beg, text, (size_t)len);
+    for (int i = 0; i < len; ++i) c->box[i] = cbox_of(text[i], weight);
+    c->nbox = len;
+    return c;
+}
+void orc_cons_free(orc_cons *c) {
+    if (!c) return;
+    free(c->txt); free(c->box); free(c);
+}
+void orc_cons_append(orc_cons *c, const char *seg, int len) {
+    memmove(c->txt + c->post, seg, (size_t)len);
+    c->post += len;
+    for (int i = 0; i < len; ++i) c->box[c->nbox++] = cbox_of(seg[i], 1);
+}
+void orc_cons_prepend(orc_cons *c, const char *seg, int len) {
+    c->pre -= len;
+    memmove(c->txt + c->pre, seg, (size_t)len);
+    memmove(c->box + len, c->box, (size_t)c->nbox * sizeof(cbox));
+    for (int i = 0; i < len; ++i) c->box[i] = cbox_of(seg[i], 1);   /* push_front from the last char backwards */
+    c->nbox += len;
+}
+
+void orc_cons_elect(orc_cons *c, int pos, int fwd, const uint8_t *ops, const char *vals, int nedit) {
+    int it = pos + c->beg - c->pre;              /* both iterators start at the box of `pos` (ref_seq.h:355,359) */
+    const int step = fwd ? 1 : -1;
+    for (int k = 0; k < nedit; ++k) {
+        if (ops[k] == 3) {                       /* DELETE: it->ignore(); ++it */
+            if (it >= 0 && it < c->nbox) c->box[it].tot++;
+            it += step;
+        } else if (ops[k] == 1) {                /* MATCH: it->select(val); ++it */
+            if (it >= 0 && it < c->nbox) { c->box[it].sel[orc_c2i(vals[k])]++; c->box[it].tot++; }
+            it += step;
+        } else if (ops[k] == 2) {                /* INSERT: forward supplies the box before `it`, backward `it` itself */
+            const int at = fwd ? it - 1 : it;
+            if (at >= 0 && at < c->nbox) c->box[at].sup[orc_c2i(vals[k])]++;
+        }
+    }
+}
+
+int orc_cons_try(orc_cons *c, orc_aligner *al, int pos, const char *seg_origin, int seg_len, int fwd, double R,
+                 int overlap_min, int32_t *out) {
+    const char *a = c->txt + c->beg + pos;                                   /* get_accessor, ref_seq.h:282-286 */
+    const int la = fwd ? c->post - c->beg - pos : pos + c->beg - c->pre + 1;
+    orc_result res;
+    uint8_t *ops = (uint8_t *)malloc((size_t)la + seg_len + 8);
+    char *vals = (char *)malloc((size_t)la + seg_len + 8);
+    int ok = 0;
+    orc_align(al, a, fwd, la, seg_origin, fwd, seg_len, R, &res, ops);       /* ref_seq.h:264: a = the reference */
+    if (res.rc >= 0 && res.matlen_a >= overlap_min) {                        /* ref_seq.h:264-265 */
+        ok = 1;
+        int j = 0;
+        for (int k = 0; k < res.nedit; ++k)                                  /* edits[k].val, seq_aligner.h:218,224 */
+            if (ops[k] == 1 || ops[k] == 2) { vals[k] = fwd ? seg_origin[j] : seg_origin[-j]; ++j; } else vals[k] = 0;
+        orc_cons_elect(c, pos, fwd, ops, vals, res.nedit);                   /* ref_seq.h:267 */
+        if (res.matlen_a == la) {                                            /* ref_seq.h:268-275 */
+            const int add = seg_len - res.matlen_b;
+            if (fwd) orc_cons_append(c, seg_origin + res.matlen_b, add);
+            else orc_cons_prepend(c, seg_origin - (seg_len - 1), add);
+        }
+    }
+    if (out) {
+        out[0] = ok; out[1] = ok ? res.matlen_b : 0; out[2] = ok ? res.cost : 0; out[3] = ok ? res.matlen_a : 0;
+        out[4] = ok ? res.nedit : 0; out[5] = c->pre - c->beg; out[6] = c->post - c->beg;
+    }
+    free(ops); free(vals);
+    return ok;
+}
+
+void orc_cons_evolve(orc_cons *c) {
+    cbox *nb = (cbox *)calloc((size_t)3 * c->max_len + 64, sizeof(cbox));
+    int nn = 0;
+    c->end = c->pre = c->beg = c->max_len;
+    char *p = c->txt + c->beg;
+    for (int i = 0; i < c->nbox; ++i) {
+        cbox cur = c->box[i], vb;
+        int has_vb = 0;
+        if ((double)cmax4(cur.sup) > 0.5 * cur.tot) {       /* has_supply(0.5): split, insert after cur */
+            memset(&vb, 0, sizeof vb);
+            memcpy(vb.sel, cur.sup, sizeof vb.sel);
+            vb.tot = cur.tot;
+            memset(cur.sup, 0, sizeof cur.sup);
+            has_vb = 1;
+        }
+        for (int rep = 0; rep <= has_vb; ++rep) {           /* cur, then the box just inserted behind it */
+            const cbox *b = rep ? &vb : &cur;
+            if ((double)cmax4(b->sel) > 0.5 * b->tot) {     /* is_valid(0.5): keep */
+                *p++ = cwinner(b->sel);
+                ++c->end;
+                nb[nn++] = *b;
+            } else if (nn > 0) {                            /* delete: the previous box absorbs its selection */
+                for (int k = 0; k < 4; ++k) nb[nn - 1].sup[k] = (uint16_t)(nb[nn - 1].sup[k] + b->sel[k]);
+            }
+        }
+    }
+    c->post = c->end;
+    free(c->box);
+    c->box = nb;
+    c->nbox = nn;
+}
+
+int orc_cons_dump(const orc_cons *c, uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *extent) {
+    for (int k = 0; k < c->nbox && k < cap; ++k) {
+        memcpy(sel + 4 * k, c->box[k].sel, 8);
+        memcpy(sup + 4 * k, c->box[k].sup, 8);
+        tot[k] = c->box[k].tot;
+    }
+    if (extent) { extent[0] = c->pre - c->beg; extent[1] = c->post - c->beg; extent[2] = c->end - c->beg; }
+    return c->nbox;
+}
+int orc_cons_text(const orc_cons *c, char *out, int cap) {
+    const int n = c->post - c->pre;
+    memcpy(out, c->txt + c->pre, (size_t)(n < cap ? n : cap));
+    return n;
+}

@@ -123,6 +123,25 @@ int orc_spaced_round(const char *ref, int ref_len, uint32_t mask, double R,
 size_t orc_open_binary(const uint8_t *buf, size_t len, uint32_t min_excl, uint32_t max_excl,
                        uint64_t *offs, size_t cap, size_t *n_total);
 
+/* ---- consensus voting and reference growth (ref_seq.h:25-188, 207-242, 259-276, 317-362) ------------------
+ * The unlocked half of ref_seq: one vote box per reference position (4 selection + 4 suppliment u16 counters and
+ * `total`), elect() applies an edit script to the boxes, evolve() turns the votes into the next reference.
+ * max_len plays MAX_SEQ_LEN (common.h:31): the text buffer holds 3*max_len chars, the origin sits at max_len. */
+typedef struct orc_cons orc_cons;
+orc_cons *orc_cons_new(const char *text, int len, int weight, int max_len);          /* ref_seq.h:218-225 */
+void      orc_cons_free(orc_cons *c);
+void      orc_cons_append(orc_cons *c, const char *seg, int len);                      /* ref_seq.h:227-233 */
+void      orc_cons_prepend(orc_cons *c, const char *seg, int len);                     /* ref_seq.h:235-242 */
+/* ref_seq.h:352-362 + apply_edits :25-41.  vals[k] = edits[k].val (the b element of a MATCH / INSERT) */
+void      orc_cons_elect(orc_cons *c, int pos, int fwd, const uint8_t *ops, const char *vals, int nedit);
+/* ref_seq::try_align, unlocked (ref_seq.h:259-276).  out: ok, matlen_b, cost, matlen_a, nedit, pre-beg, post-beg */
+int       orc_cons_try(orc_cons *c, orc_aligner *al, int pos, const char *seg_origin, int seg_len, int fwd,
+                       double R, int overlap_min, int32_t *out);
+void      orc_cons_evolve(orc_cons *c);                                                /* ref_seq.h:317-349 */
+/* vote list in list order; extent = {pre-beg, post-beg, end-beg}; returns the number of boxes */
+int       orc_cons_dump(const orc_cons *c, uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *extent);
+int       orc_cons_text(const orc_cons *c, char *out, int cap);                        /* text [pre, post) */
+
 #ifdef __cplusplus
 }
 #endif

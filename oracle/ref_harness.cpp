@@ -12,6 +12,9 @@
  *   reference (called, not restated): dna_seq::{encode,decode,seed_at,text2bin,bin2text},
  *     seq_aligner<>::align and its public result fields, ref_seq::{get_seedmap,get_accessor},
  *     hash_table.
+ *   reference, consensus half (ref_cons_*): ref_seq's constructor, try_align (unlocked: elect, append, prepend),
+ *     evolve, get_accessor; the vote list is read through the private members (`#define private public`
+ *     around the include -- the header itself is untouched).
  *   this file: the driver loops of locator.cpp:62-92 and spaced_seed.cpp:262-298,420-437
  *     (those live in main() files and cannot be linked), with R / trials / buffer sizes
  *     as parameters, plus the canonicalisation of SURVEY A.4 / B3 / B4:
@@ -30,7 +33,9 @@
 #include "common.h"
 #include "dna_seq.h"
 #include "seq_aligner.h"
+#define private public          /* the consensus entry points below read ref_seq's vote list (ref_seq.h:359-369) */
 #include "ref_seq.h"
+#undef private
 
 typedef seq_aligner<40000, 12288> big_aligner;
 static big_aligner *g_big = NULL;
@@ -241,6 +246,55 @@ int ref_spaced_round(const char *ref, int ref_len, uint32_t mask, double R, int 
     }
     delete pref;
     return 0;
+}
+
+
+/* ---- consensus voting and reference growth (ref_seq.h:25-188, 259-276, 317-362) -------------------------------
+ * One ref_seq at a time, driven from Python: new -> try* -> dump / evolve -> ... -> free.
+ * try_align needs the stock t_aligner (seq_aligner<26000,6000>); OVERLAP_MIN is the reference's 64. */
+static ref_seq *g_cons = NULL;
+
+int ref_cons_new(const char *text, int len, int weight) {
+    delete g_cons;
+    g_cons = new ref_seq(text, len, false, weight);
+    return 0;
+}
+void ref_cons_free(void) { delete g_cons; g_cons = NULL; }
+
+/* out: ok, matlen_b, cost, matlen_a, nedit (all 0 unless ok), pre-beg, post-beg after the call */
+int ref_cons_try(int pos, char *seg_origin, int seg_len, int fwd, double R, int32_t *out) {
+    if (!g_stock) g_stock = new t_aligner();
+    g_stock->R = R;
+    seq_accessor ac(seg_origin, fwd != 0, seg_len);
+    seq_accessor ar = g_cons->get_accessor(pos, fwd != 0);
+    canonicalise(g_stock, ar.length(), seg_len);
+    bool ok = g_cons->try_align(g_stock, pos, &ac);
+    out[0] = ok; out[1] = ok ? g_stock->matlen_b : 0; out[2] = ok ? g_stock->final_cost() : 0; out[3] = ok ? g_stock->matlen_a : 0;
+    out[4] = ok ? g_stock->nedit : 0; out[5] = g_cons->pre - g_cons->beg; out[6] = g_cons->post - g_cons->beg;
+    return ok;
+}
+
+void ref_cons_evolve(void) { g_cons->evolve(); }
+
+/* the vote list in list order: sel[4k..], sup[4k..], tot[k]; returns the number of boxes */
+int ref_cons_dump(uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *extent) {
+    int n = 0;
+    for (std::list<vote_box>::iterator it = g_cons->consensus.begin(); it != g_cons->consensus.end(); ++it, ++n) {
+        if (n >= cap) continue;
+        for (int c = 0; c < 4; ++c) { sel[4 * n + c] = it->selection.acgt[c]; sup[4 * n + c] = it->suppliment.acgt[c]; }
+        tot[n] = it->total;
+    }
+    if (extent) {
+        extent[0] = g_cons->pre - g_cons->beg; extent[1] = g_cons->post - g_cons->beg; extent[2] = g_cons->end - g_cons->beg;
+    }
+    return n;
+}
+
+/* text [pre, post) as get_accessor sees it; returns its length */
+int ref_cons_text(char *out, int cap) {
+    int n = g_cons->post - g_cons->pre;
+    memcpy(out, g_cons->txt_buf + g_cons->pre, n < cap ? n : cap);
+    return n;
 }
 
 }  /* extern "C" */

@@ -101,6 +101,15 @@ SYMBOLS = {
     "pba_overlap_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pba_overlap_all_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int,
                                          C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
+    "pba_cons_create": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pba_cons_destroy": (None, [_P]),
+    "pba_cons_extent": (C.c_int, [_P, _P]),
+    "pba_cons_append": (C.c_int, [_P, _P, C.c_char_p, C.c_int]),
+    "pba_cons_prepend": (C.c_int, [_P, _P, C.c_char_p, C.c_int]),
+    "pba_cons_elect": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
+    "pba_cons_evolve": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
+    "pba_cons_dump": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
+    "pba_cons_text": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "pba_strerror": (C.c_char_p, [C.c_int]),
 }
 

@@ -15,6 +15,7 @@
 #include "align_bitvec.h"
 #include "align_bvtrace.h"
 #include "align_rowsweep.h"
+#include "consensus.h"
 #include "dev_common.h"
 #include "pba.h"
 #include "pba_internal.h"
@@ -1571,6 +1572,177 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     (void)hipEventElapsedTime(&st.sort_ms, ctx->ev[3], ctx->ev[4]);
     (void)hipEventElapsedTime(&st.walk_ms, ctx->ev[4], ctx->ev[5]);
     if (stats) *stats = st;
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: consensus voting and reference growth (ref_seq.h, the unlocked half)
+// ---------------------------------------------------------------------------------------------
+struct pba_cons {
+    pba_ctx *ctx;
+    int max_len, beg, end, pre, post;     // as in ref_seq (ref_seq.h:364-368), indices into the 3*max_len arrays
+    int cur;                              // which of the two array sets is live (evolve ping-pongs)
+    ConsDev set[2];
+    int *d_n;
+};
+
+static void cons_free_sets(pba_cons *c) {
+    for (int k = 0; k < 2; ++k) {
+        if (c->set[k].sel) (void)hipFree(c->set[k].sel);
+        if (c->set[k].sup) (void)hipFree(c->set[k].sup);
+        if (c->set[k].tot) (void)hipFree(c->set[k].tot);
+        if (c->set[k].txt) (void)hipFree(c->set[k].txt);
+    }
+    if (c->d_n) (void)hipFree(c->d_n);
+}
+
+static int cons_fill(pba_ctx *ctx, pba_cons *c, int first, const char *text, int len, int weight) {
+    if (len <= 0) return PBA_OK;
+    DevBuf d_text;
+    HIPCHK(hipMalloc(&d_text.p, (size_t)len));
+    HIPCHK(hipMemcpyAsync(d_text.p, text, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_cons_fill, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, ctx->stream, c->set[c->cur], first,
+                       len, d_text.as<char>(), weight);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_cons_create(pba_ctx *ctx, const char *text, int len, int weight, int max_len, pba_cons **out) {
+    if (!ctx || !out || len < 0 || (!text && len) || max_len < 1 || len > max_len || weight < 0 || weight > 0xFFFF)
+        return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    pba_cons *c = new (std::nothrow) pba_cons();
+    if (!c) return PBA_E_NOMEM;
+    memset(c, 0, sizeof *c);
+    c->ctx = ctx; c->max_len = max_len;
+    c->beg = c->pre = max_len; c->end = c->post = max_len + len;
+    const size_t cap = (size_t)3 * max_len + 64;
+    bool ok = hipMalloc((void **)&c->d_n, sizeof(int)) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipMalloc((void **)&c->set[k].sel, cap * 8) == hipSuccess && hipMalloc((void **)&c->set[k].sup, cap * 8) == hipSuccess &&
+             hipMalloc((void **)&c->set[k].tot, cap * 4) == hipSuccess && hipMalloc((void **)&c->set[k].txt, cap) == hipSuccess;
+    if (!ok) { cons_free_sets(c); delete c; PBA_FAIL(PBA_E_NOMEM, "pba_cons_create"); }
+    int st = cons_fill(ctx, c, c->beg, text, len, weight);                    // ref_seq.h:218-225
+    if (st != PBA_OK) { cons_free_sets(c); delete c; return st; }
+    *out = c;
+    return PBA_OK;
+}
+
+void pba_cons_destroy(pba_cons *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    cons_free_sets(c);
+    delete c;
+}
+
+int pba_cons_extent(const pba_cons *c, int32_t *extent) {
+    if (!c || !extent) return PBA_E_INVALID;
+    extent[0] = c->pre - c->beg; extent[1] = c->post - c->beg; extent[2] = c->end - c->beg;
+    return PBA_OK;
+}
+
+int pba_cons_append(pba_ctx *ctx, pba_cons *c, const char *seg, int len) {        // ref_seq.h:227-233
+    if (!ctx || !c || len < 0 || (!seg && len)) return PBA_E_INVALID;
+    if ((long long)c->post + len > 3ll * c->max_len) PBA_FAIL(PBA_E_TOOLONG, "pba_cons_append: reference grew past 2*max_len");
+    HIPCHK(hipSetDevice(ctx->device));
+    int st = cons_fill(ctx, c, c->post, seg, len, 1);
+    if (st == PBA_OK) c->post += len;
+    return st;
+}
+
+int pba_cons_prepend(pba_ctx *ctx, pba_cons *c, const char *seg, int len) {       // ref_seq.h:235-242
+    if (!ctx || !c || len < 0 || (!seg && len)) return PBA_E_INVALID;
+    if (c->pre - len < 0) PBA_FAIL(PBA_E_TOOLONG, "pba_cons_prepend: reference grew past max_len before its origin");
+    HIPCHK(hipSetDevice(ctx->device));
+    int st = cons_fill(ctx, c, c->pre - len, seg, len, 1);
+    if (st == PBA_OK) c->pre -= len;
+    return st;
+}
+
+int pba_cons_elect(pba_ctx *ctx, pba_cons *c, uint32_t n, const int32_t *pos, const uint8_t *fwd, const uint8_t *ops,
+                   const char *vals, const uint64_t *ops_off, const int32_t *nedit) {
+    if (!ctx || !c || (n && (!pos || !fwd || !ops || !vals || !ops_off || !nedit))) return PBA_E_INVALID;
+    if (n == 0) return PBA_OK;
+    for (uint32_t q = 0; q < n; ++q)
+        if (nedit[q] < 0 || ops_off[q + 1] < ops_off[q] || (uint64_t)nedit[q] > ops_off[q + 1] - ops_off[q] ||
+            c->beg + pos[q] < c->pre || c->beg + pos[q] >= c->post)              // "pos should be contained", ref_seq.h:351
+            PBA_FAIL(PBA_E_INVALID, "pba_cons_elect: script outside its slot or position outside the reference");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t total = ops_off[n] - ops_off[0];
+    DevBuf d_pos, d_fwd, d_ops, d_vals, d_off, d_ne;
+    HIPCHK(hipMalloc(&d_pos.p, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&d_fwd.p, n));
+    HIPCHK(hipMalloc(&d_ops.p, total + 16));
+    HIPCHK(hipMalloc(&d_vals.p, total + 16));
+    HIPCHK(hipMalloc(&d_off.p, sizeof(uint64_t) * (n + 1)));
+    HIPCHK(hipMalloc(&d_ne.p, sizeof(int32_t) * n));
+    std::vector<uint64_t> rel(n + 1);
+    for (uint32_t q = 0; q <= n; ++q) rel[q] = ops_off[q] - ops_off[0];
+    HIPCHK(hipMemcpyAsync(d_pos.p, pos, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_fwd.p, fwd, n, hipMemcpyHostToDevice, ctx->stream));
+    if (total) {
+        HIPCHK(hipMemcpyAsync(d_ops.p, ops + ops_off[0], total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_vals.p, vals + ops_off[0], total, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipMemcpyAsync(d_off.p, rel.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_ne.p, nedit, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_cons_elect, dim3(n), dim3(PBA_WAVE), 0, ctx->stream, c->set[c->cur], c->beg, c->pre, c->post, n,
+                       d_pos.as<int>(), d_fwd.as<uint8_t>(), d_ops.as<uint8_t>(), d_vals.as<char>(),
+                       d_off.as<unsigned long long>(), d_ne.as<int>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_cons_evolve(pba_ctx *ctx, pba_cons *c, char *text_out, int cap, int32_t *new_len) {   // ref_seq.h:317-349
+    if (!ctx || !c || !new_len || cap < 0 || (!text_out && cap)) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nxt = c->cur ^ 1;
+    hipLaunchKernelGGL(k_cons_evolve, dim3(1), dim3(1024), 0, ctx->stream, c->set[c->cur], c->set[nxt], c->pre, c->post,
+                       c->max_len, c->d_n);
+    HIPCHK(hipGetLastError());
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, c->d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    c->cur = nxt;
+    c->beg = c->pre = c->max_len;
+    c->end = c->post = c->max_len + n;
+    *new_len = n;
+    const int ncopy = std::min(n, cap);
+    if (ncopy > 0) {
+        HIPCHK(hipMemcpyAsync(text_out, c->set[c->cur].txt + c->beg, (size_t)ncopy, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return PBA_OK;
+}
+
+int pba_cons_dump(pba_ctx *ctx, const pba_cons *c, uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *n) {
+    if (!ctx || !c || !n || cap < 0 || (cap && (!sel || !sup || !tot))) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    *n = c->post - c->pre;
+    const int k = std::min(*n, cap);
+    if (k > 0) {
+        const ConsDev &d = c->set[c->cur];
+        HIPCHK(hipMemcpyAsync(sel, d.sel + c->pre, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(sup, d.sup + c->pre, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(tot, d.tot + c->pre, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return PBA_OK;
+}
+
+int pba_cons_text(pba_ctx *ctx, const pba_cons *c, char *out, int cap, int32_t *n) {
+    if (!ctx || !c || !n || cap < 0 || (cap && !out)) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    *n = c->post - c->pre;
+    const int k = std::min(*n, cap);
+    if (k > 0) {
+        HIPCHK(hipMemcpyAsync(out, c->set[c->cur].txt + c->pre, (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return PBA_OK;
 }
 

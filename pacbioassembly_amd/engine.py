@@ -343,6 +343,81 @@ class SeqSet:
         return buf.raw[:ln]
 
 
+class Consensus:
+    """Vote boxes of an unlocked reference, resident in HBM (ref_seq.h: base_vote, vote_box, elect, evolve)."""
+
+    def __init__(self, ctx: "Context", text: bytes, weight: int = 1, max_len: int = 0):
+        self.ctx = ctx
+        self.max_len = max_len or max(4 * len(text), 100000)
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.pba_cons_create(ctx.h, text, len(text), weight, self.max_len, C.byref(self.h)), "cons_create")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.pba_cons_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def extent(self):
+        e = np.zeros(3, np.int32)
+        self.ctx.check(self.ctx.lib.pba_cons_extent(self.h, _ptr(e)))
+        return e.tolist()
+
+    def append(self, seg: bytes):
+        self.ctx.check(self.ctx.lib.pba_cons_append(self.ctx.h, self.h, seg, len(seg)), "cons_append")
+
+    def prepend(self, seg: bytes):
+        self.ctx.check(self.ctx.lib.pba_cons_prepend(self.ctx.h, self.h, seg, len(seg)), "cons_prepend")
+
+    def elect(self, pos, fwd, scripts, vals):
+        """scripts / vals: one uint8 op array and one bytes object per script (vals[k] = the b element of op k)."""
+        n = len(scripts)
+        off = np.zeros(n + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in scripts])
+        ops = np.concatenate([np.asarray(x, np.uint8) for x in scripts] + [np.zeros(1, np.uint8)])
+        vb = np.frombuffer(b"".join(vals) + b"\0", np.uint8)
+        ne = np.array([len(x) for x in scripts], np.int32)
+        pos = np.ascontiguousarray(pos, np.int32); fw = np.ascontiguousarray(fwd, np.uint8)
+        self.ctx.check(self.ctx.lib.pba_cons_elect(self.ctx.h, self.h, n, _ptr(pos), _ptr(fw), _ptr(ops), _ptr(vb), _ptr(off),
+                                                   _ptr(ne)), "cons_elect")
+
+    def evolve(self) -> bytes:
+        cap = 3 * self.max_len
+        buf = C.create_string_buffer(cap)
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.pba_cons_evolve(self.ctx.h, self.h, buf, cap, C.byref(n)), "cons_evolve")
+        return buf.raw[:n.value]
+
+    def dump(self):
+        e = self.extent()
+        cap = e[1] - e[0]
+        sel = np.zeros((max(cap, 1), 4), np.uint16); sup = np.zeros((max(cap, 1), 4), np.uint16); tot = np.zeros(max(cap, 1), np.int32)
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.pba_cons_dump(self.ctx.h, self.h, _ptr(sel), _ptr(sup), _ptr(tot), cap, C.byref(n)), "cons_dump")
+        return sel[:n.value], sup[:n.value], tot[:n.value], e
+
+    def text(self) -> bytes:
+        e = self.extent()
+        cap = e[1] - e[0]
+        buf = C.create_string_buffer(cap + 1)
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.pba_cons_text(self.ctx.h, self.h, buf, cap, C.byref(n)), "cons_text")
+        return buf.raw[:n.value]
+
+
+def script_vals(ops: np.ndarray, seg: bytes, fwd: bool = True) -> bytes:
+    """edits[k].val of an edit script (seq_aligner.h:218,224): the b element a MATCH / INSERT consumes, 0 for a DELETE.
+    seg: the accessor's elements in memory order (a backward accessor starts at its last byte)."""
+    elems = np.frombuffer(seg if fwd else seg[::-1], np.uint8)
+    ops = np.asarray(ops, np.uint8)
+    takes = ops != 3
+    idx = np.cumsum(takes) - 1
+    out = np.where(takes, elems[np.minimum(idx, max(elems.size - 1, 0))] if elems.size else 0, 0).astype(np.uint8)
+    return out.tobytes()
+
+
 class SeedIndex:
     def __init__(self, ctx: Context, h):
         self.ctx, self.h = ctx, h

@@ -80,6 +80,15 @@ class Oracle:
         L.orc_open_binary.argtypes = [_P, C.c_size_t, C.c_uint32, C.c_uint32, _P, C.c_size_t, _P]
         L.orc_prefault.restype = C.c_int; L.orc_prefault.argtypes = [C.c_int, C.c_int, C.c_double]
         L.orc_pool_release.restype = None; L.orc_pool_release.argtypes = []
+        L.orc_cons_new.restype = _P; L.orc_cons_new.argtypes = [_P, C.c_int, C.c_int, C.c_int]
+        L.orc_cons_free.argtypes = [_P]
+        L.orc_cons_try.restype = C.c_int
+        L.orc_cons_try.argtypes = [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, _P]
+        L.orc_cons_elect.argtypes = [_P, C.c_int, C.c_int, _P, _P, C.c_int]
+        L.orc_cons_append.argtypes = [_P, _P, C.c_int]; L.orc_cons_prepend.argtypes = [_P, _P, C.c_int]
+        L.orc_cons_evolve.argtypes = [_P]
+        L.orc_cons_dump.restype = C.c_int; L.orc_cons_dump.argtypes = [_P, _P, _P, _P, C.c_int, _P]
+        L.orc_cons_text.restype = C.c_int; L.orc_cons_text.argtypes = [_P, _P, C.c_int]
         self._aligner = None
 
     def prefault(self, nthreads: int, len_a: int, R: float):
@@ -118,6 +127,10 @@ class Oracle:
 
     def mask_from_pattern(self, pat: str) -> int:
         return self.lib.orc_mask_from_pattern(pat.encode())
+
+    def consensus(self, text: bytes, weight: int = 1, max_len: int = 0, overlap_min: int = 64):
+        """The unlocked ref_seq (votes, growth, evolve) as restated by the oracle."""
+        return OracleCons(self, text, weight, max_len or max(4 * len(text), 100000), overlap_min)
 
     # DP
     def align(self, a: bytes, b: bytes, R: float, a_fwd=True, b_fwd=True, maxn=0, maxm=0, want_ops=False):
@@ -194,6 +207,85 @@ def have_ref() -> bool:
     return os.path.exists(REF_SO)
 
 
+class _ConsBase:
+    """Common face of the oracle's and the reference's consensus objects: try_align / evolve / dump / text."""
+
+    def try_align(self, pos: int, seg: bytes, fwd: bool, R: float = 0.3):
+        """seg holds the accessor's elements in memory order (backward: the accessor starts at the last byte).
+        Returns dict(ok, matlen_b, cost, matlen_a, nedit, pre, post)."""
+        buf = np.frombuffer(b"\0" * 8 + seg + b"\0" * 8, np.uint8)
+        origin = buf.ctypes.data + 8 + (0 if fwd or not seg else len(seg) - 1)
+        out = np.zeros(7, np.int32)
+        self._try(pos, origin, len(seg), int(fwd), R, out)
+        return dict(zip(("ok", "matlen_b", "cost", "matlen_a", "nedit", "pre", "post"), out.tolist()))
+
+    def dump(self, cap: int = 1 << 22):
+        sel = np.zeros((cap, 4), np.uint16); sup = np.zeros((cap, 4), np.uint16); tot = np.zeros(cap, np.int32)
+        ext = np.zeros(3, np.int32)
+        n = self._dump(sel, sup, tot, cap, ext)
+        return sel[:n].copy(), sup[:n].copy(), tot[:n].copy(), ext.tolist()
+
+    def text(self, cap: int = 1 << 22) -> bytes:
+        b = C.create_string_buffer(cap)
+        n = self._text(b, cap)
+        return b.raw[:n]
+
+
+class OracleCons(_ConsBase):
+    def __init__(self, orc, text, weight, max_len, overlap_min):
+        self.orc, self.overlap_min = orc, overlap_min
+        self.h = orc.lib.orc_cons_new(text, len(text), weight, max_len)
+        self.al = orc.lib.orc_aligner_new(26000, 6000)          # t_aligner, seq_aligner.h:260
+
+    def _try(self, pos, origin, n, fwd, R, out):
+        self.orc.lib.orc_cons_try(self.h, self.al, pos, C.c_void_p(origin), n, fwd, R, self.overlap_min, _ptr(out))
+
+    def elect(self, pos: int, fwd: bool, ops: np.ndarray, vals: bytes):
+        ops = np.ascontiguousarray(ops, np.uint8)
+        self.orc.lib.orc_cons_elect(self.h, pos, int(fwd), _ptr(ops), vals, ops.size)
+
+    def append(self, seg: bytes):
+        self.orc.lib.orc_cons_append(self.h, seg, len(seg))
+
+    def prepend(self, seg: bytes):
+        self.orc.lib.orc_cons_prepend(self.h, seg, len(seg))
+
+    def evolve(self):
+        self.orc.lib.orc_cons_evolve(self.h)
+
+    def _dump(self, sel, sup, tot, cap, ext):
+        return self.orc.lib.orc_cons_dump(self.h, _ptr(sel), _ptr(sup), _ptr(tot), cap, _ptr(ext))
+
+    def _text(self, b, cap):
+        return self.orc.lib.orc_cons_text(self.h, b, cap)
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_cons_free(self.h); self.orc.lib.orc_aligner_free(self.al)
+        except Exception:
+            pass
+
+
+class RefCons(_ConsBase):
+    """ref_seq itself (one live object per process), OVERLAP_MIN = 64 as compiled."""
+
+    def __init__(self, ref, text, weight):
+        self.lib = ref.lib
+        self.lib.ref_cons_new(text, len(text), weight)
+
+    def _try(self, pos, origin, n, fwd, R, out):
+        self.lib.ref_cons_try(pos, C.c_void_p(origin), n, fwd, C.c_double(R), _ptr(out))
+
+    def evolve(self):
+        self.lib.ref_cons_evolve()
+
+    def _dump(self, sel, sup, tot, cap, ext):
+        return self.lib.ref_cons_dump(_ptr(sel), _ptr(sup), _ptr(tot), cap, _ptr(ext))
+
+    def _text(self, b, cap):
+        return self.lib.ref_cons_text(b, cap)
+
+
 class Ref:
     """The reference itself (oracle/_ref/libpba_ref.so); build container only."""
 
@@ -218,6 +310,13 @@ class Ref:
         L.ref_locator.argtypes = [_P, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]
         L.ref_spaced_round.restype = C.c_int
         L.ref_spaced_round.argtypes = [_P, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_int, _P, _P, C.c_int, _P]
+        L.ref_cons_new.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.ref_cons_try.restype = C.c_int; L.ref_cons_try.argtypes = [C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]
+        L.ref_cons_dump.restype = C.c_int; L.ref_cons_dump.argtypes = [_P, _P, _P, C.c_int, _P]
+        L.ref_cons_text.restype = C.c_int; L.ref_cons_text.argtypes = [_P, C.c_int]
+
+    def consensus(self, text: bytes, weight: int = 1):
+        return RefCons(self, text, weight)
 
     def encode(self, t: bytes) -> int:
         return self.lib.ref_encode(t)

@@ -607,3 +607,74 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     torch.cuda.synchronize()
     got2, st2 = ctx.overlap_all_probes(S, gathered.data_ptr(), gathered.numel(), mask, 0.30, 32, 64, kernel=kernel)
     assert [tuple(int(x) for x in r) for r in got2] == want and st2["n_probe_entries"] == st["n_probe_entries"]
+
+
+# ----------------------------------------------------------------------------- consensus (ref_seq, unlocked)
+class GpuCons:
+    """ref_seq::try_align (ref_seq.h:259-276) composed from the C ABI: align + edit script on the GPU, votes and
+    growth in the device-resident vote boxes (pba_cons_*).  Same face as the oracle's / reference's objects."""
+
+    def __init__(self, ctx, text, weight):
+        self.ctx = ctx
+        self.c = eng.Consensus(ctx, text, weight)
+
+    def try_align(self, pos, seg, fwd, R=0.3):
+        e = self.c.extent()
+        text = self.c.text()
+        at = pos - e[0]                                         # index of reference position `pos` inside [pre, post)
+        a = text[at:] if fwd else text[:at + 1]                 # get_accessor, ref_seq.h:282-286
+        res, ops = self.ctx.align_text_trace(a, seg, R, fwd, fwd, maxn=26000, maxm=6000)   # t_aligner; a = the reference
+        ok = int(res["rc"]) >= 0 and int(res["matlen_a"]) >= 64
+        if ok:
+            self.c.elect([pos], [fwd], [ops], [eng.script_vals(ops, seg, fwd)])
+            if int(res["matlen_a"]) == len(a):
+                add = len(seg) - int(res["matlen_b"])
+                if fwd:
+                    self.c.append(seg[len(seg) - add:] if add else b"")
+                else:
+                    self.c.prepend(seg[:add])
+        e = self.c.extent()
+        return {"ok": int(ok), "matlen_b": int(res["matlen_b"]) if ok else 0, "cost": int(res["cost"]) if ok else 0,
+                "matlen_a": int(res["matlen_a"]) if ok else 0, "nedit": int(ops.size) if ok else 0, "pre": e[0], "post": e[1]}
+
+    def dump(self):
+        return self.c.dump()
+
+    def text(self):
+        return self.c.text()
+
+    def evolve(self):
+        self.c.evolve()
+
+
+def test_consensus_golden_and_oracle(ctx, oracle):
+    """Votes (k_cons_elect), growth and evolve (k_cons_evolve) against what the reference itself produced
+    (tests/golden/consensus.json) and, on a fresh scenario, against the oracle; then a batch elect of all scripts of a
+    round at once against the one-by-one result (votes commute)."""
+    from cons_scenarios import SCENARIOS, round_tries, run_scenario, scenario_inputs
+    gold = {g["name"]: g for g in gold_json("consensus.json")}
+    for sc in SCENARIOS:
+        text, weight, reads = scenario_inputs(sc)
+        got = run_scenario(GpuCons(ctx, text, weight), reads)
+        for k, (a, b) in enumerate(zip(got["rounds"], gold[sc[0]]["rounds"])):
+            assert a["tries"] == b["tries"], (sc[0], k)
+            assert a["before_evolve"] == b["before_evolve"], (sc[0], k)
+            assert a["after_evolve"] == b["after_evolve"], (sc[0], k)
+    sc = ("fresh_gpu", 141, 142, 7000, 1500, 3200, 70, 1100, 2, (0.06, 0.04, 0.04), True)
+    text, weight, reads = scenario_inputs(sc)
+    assert run_scenario(GpuCons(ctx, text, weight), reads) == run_scenario(oracle.consensus(text, weight), reads)
+    # batch form: every forward script of round 0 in one pba_cons_elect call (no growth: interior tries only)
+    one, many = eng.Consensus(ctx, text, weight), eng.Consensus(ctx, text, weight)
+    pos, fw, scripts, vals = [], [], [], []
+    for hit, r, seg, fwd in round_tries(text, reads, 0):
+        a = text[hit:] if fwd else text[:hit + 1]
+        res, ops = ctx.align_text_trace(a, seg, 0.3, fwd, fwd)
+        if int(res["rc"]) < 0:
+            continue
+        one.elect([hit], [fwd], [ops], [eng.script_vals(ops, seg, fwd)])
+        pos.append(hit); fw.append(fwd); scripts.append(ops); vals.append(eng.script_vals(ops, seg, fwd))
+    assert len(pos) >= 8
+    many.elect(pos, fw, scripts, vals)
+    for x, y in zip(one.dump()[:3], many.dump()[:3]):
+        assert (x == y).all()
+    assert one.evolve() == many.evolve()

@@ -149,3 +149,21 @@ def test_spaced_round(oracle, name):
         else:
             assert (rows[col] == want[:, ci]).all(), (name, col)
     assert int(rows["found"].sum()) == meta["found"]
+
+
+# ----------------------------------------------------------------------------- consensus (ref_seq, unlocked)
+def test_consensus_golden(oracle):
+    """ref_seq::try_align (elect, append, prepend) and evolve, two rounds per scenario: the oracle's restatement
+    reproduces what the reference itself produced (tests/golden/consensus.json) -- every try's outcome, the vote
+    boxes before and after evolve, the evolved text."""
+    from cons_scenarios import SCENARIOS, run_scenario, scenario_inputs
+    gold = {g["name"]: g for g in gold_json("consensus.json")}
+    for sc in SCENARIOS:
+        text, weight, reads = scenario_inputs(sc)
+        got = run_scenario(oracle.consensus(text, weight), reads)
+        want = gold[sc[0]]
+        for k, (a, b) in enumerate(zip(got["rounds"], want["rounds"])):
+            assert a["tries"] == b["tries"], (sc[0], k)
+            assert a["before_evolve"] == b["before_evolve"], (sc[0], k)
+            assert a["after_evolve"] == b["after_evolve"], (sc[0], k)
+        assert sum(t[4] for r in want["rounds"] for t in r["tries"]) >= 12

@@ -78,3 +78,15 @@ def test_index_and_locator_random(oracle, ref):
     for c in r1.dtype.names:
         assert (r1[c] == r2[c]).all(), c
     assert all(s1[k] == s2[k] for k in s2)
+
+
+def test_consensus_fresh_inputs(oracle, ref):
+    """Consensus voting / growth / evolve on seeds the goldens do not hold: oracle == reference, step by step."""
+    from cons_scenarios import run_scenario, scenario_inputs
+    for sc in [("fresh_a", 131, 132, 7000, 1500, 3200, 70, 1100, 2, (0.06, 0.04, 0.04), True),
+               ("fresh_b", 133, 134, 6000, 2000, 2500, 50, 900, 1, (0.02, 0.08, 0.03), False)]:
+        text, weight, reads = scenario_inputs(sc)
+        a = run_scenario(oracle.consensus(text, weight), reads)
+        b = run_scenario(ref.consensus(text, weight), reads)
+        assert a == b, sc[0]
+        assert sum(t[4] for r in b["rounds"] for t in r["tries"]) >= 8
