@@ -1,5 +1,6 @@
 // compat_test.cpp -- the reference's own unit-test expectations (test/dna_test.cpp, test/aligner_test.cpp,
-// test/ref_test.cpp "basic"), restated against include/compat/*.h, i.e. running on the MI355X through libpba.so.
+// test/ref_test.cpp: all twelve cases), restated against include/compat/*.h, i.e. running on the MI355X through
+// libpba.so (OVERLAP_MIN = 16 as SURVEY B9 records: at the reference's 64 its own 43-base cases cannot pass).
 // Own code: only the known-answer values are the reference's.  Exit code 0 = all passed.
 #define OVERLAP_MIN 16
 #define PBA_COMPAT_QUIET
@@ -133,11 +134,144 @@ static void ref_basic() {              // test/ref_test.cpp:100-128
     delete pref;
 }
 
+// test/ref_test.cpp:131-254 -- the unlocked reference: votes, growth, evolve.  The known-answer strings are the
+// reference's (test/ref_test.cpp:71-80); each case starts from a fresh ref_seq of dna_txt like its SetUp does.
+static char r_txt[]  = "ACGTAACCGGTTAAACCCGGGTTTTGCAAAAAAAAAAAAAAAA";
+static char r_txt1[] = "ACGTAACCGGTTAAACCCGGGTGTTGCAAAAAAAAAAAAAAAA";
+static char r_txt2[] = "ACGTAACCGGTTAAACCCGGGTTGTTGCAAAAAAAAAAAAAAAA";
+static char r_txt3[] = "ACGTAACCGGTTAAACCCGGGTTGGTTGCAAAAAAAAAAAAAAAA";
+static char r_txt4[] = "ACGTAACCGGTTAAACCCGGGTTGTTGCAAAAAAAAAAAAAAAAGGCCTTAA";
+static char r_txt5[] = "ACGTAACCGGTTAAACCCGGGTTGTTGCAAAAAAAAAAAAAAAAGGCCTTAAC";
+static char r_txt6[] = "TTTTACGTAACCGGTTAAACCCGGGTTGTTGCAAAAAAAAAAAAAAAA";
+static char r_txt7[] = "TTTTTACGTAACCGGTTAAACCCGGGTTGTTGCAAAAAAAAAAAAAAAA";
+
+struct RefCase {
+    ref_seq *pref;
+    t_aligner *pal;
+    int sz;
+    RefCase() {
+        unsigned char bseg[24];
+        sz = (int)strlen(r_txt);
+        dna_seq::text2bin(r_txt, bseg, 24);
+        pref = new ref_seq(bseg);
+        pal = new t_aligner();
+    }
+    ~RefCase() { delete pref; delete pal; }
+    bool reads_forward(const char *want, int n) {          // the reference from position 0 reads `want`
+        seq_accessor a = pref->get_accessor(0, true);
+        for (int i = 0; i < n; ++i) if (want[i] != a.next()) return false;
+        return true;
+    }
+    bool reads_backward(const char *want, int from) {      // ... and backwards from position `from`
+        seq_accessor a = pref->get_accessor(from, false);
+        for (int i = from; i >= 0; --i) if (want[i] != a.next()) return false;
+        return true;
+    }
+};
+
+static void ref_unlocked() {
+    {   // grow, :131-142
+        RefCase c;
+        char post[] = "CGT", pre[] = "TGC";
+        c.pref->append(post, 3);
+        CHECK(c.pref->contained(c.sz + 2)); CHECK(!c.pref->contained(c.sz + 3));
+        c.pref->prepend(pre, 3);
+        CHECK(c.pref->contained(-3)); CHECK(!c.pref->contained(-4));
+        CHECK((unsigned)c.sz == c.pref->length());
+    }
+    {   // change, :144-154: two votes for a substitution beat the reference's own
+        RefCase c;
+        seq_accessor seg(r_txt1, true, (int)strlen(r_txt1));
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        seg.reset(0);
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        c.pref->evolve();
+        CHECK(c.reads_forward(r_txt1, (int)strlen(r_txt1)));
+    }
+    {   // remove, :156-166: the first base is voted out
+        RefCase c;
+        seq_accessor seg(r_txt + 1, true, c.sz - 1);
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        seg.reset(0);
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        c.pref->evolve();
+        CHECK((unsigned)(c.sz - 1) == c.pref->length());
+        CHECK(c.reads_forward(r_txt + 1, c.sz - 1));
+    }
+    {   // insert, :168-180
+        RefCase c;
+        const int n = (int)strlen(r_txt2);
+        seq_accessor seg(r_txt2, true, n);
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        CHECK(n == c.pal->nedit);
+        seg.reset(0);
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        c.pref->evolve();
+        CHECK((unsigned)n == c.pref->length());
+        CHECK(c.reads_forward(r_txt2, n));
+    }
+    {   // insert2, :182-191: one vote for two inserted bases: only one of them gets a box of its own
+        RefCase c;
+        seq_accessor seg(r_txt3, true, (int)strlen(r_txt3));
+        CHECK(c.pref->try_align(c.pal, 0, &seg));
+        c.pref->evolve();
+        CHECK((unsigned)(c.sz + 1) == c.pref->length());
+        CHECK(c.reads_forward(r_txt2, c.sz + 1));
+    }
+    {   // back_insert, :193-209
+        RefCase c;
+        const int n = (int)strlen(r_txt2);
+        seq_accessor seg(r_txt2 + n - 1, false, n);
+        CHECK(c.pref->try_align(c.pal, c.sz - 1, &seg));
+        CHECK(n == c.pal->nedit);
+        seg.reset(0);
+        CHECK(c.pref->try_align(c.pal, c.sz - 1, &seg));
+        c.pref->evolve();
+        CHECK((unsigned)n == c.pref->length());
+        CHECK(c.reads_backward(r_txt2, n - 1));
+    }
+    {   // back_insert2, :211-221
+        RefCase c;
+        const int n = (int)strlen(r_txt3);
+        seq_accessor seg(r_txt3 + n - 1, false, n);
+        CHECK(c.pref->try_align(c.pal, c.sz - 1, &seg));
+        CHECK(n == c.pal->nedit);
+        c.pref->evolve();
+        CHECK((unsigned)(c.sz + 1) == c.pref->length());
+        CHECK(c.reads_backward(r_txt2, c.sz));
+    }
+    {   // append, :223-236: a read running off the end grows the reference
+        RefCase c;
+        seq_accessor s4(r_txt4, true, (int)strlen(r_txt4));
+        CHECK(c.pref->try_align(c.pal, 0, &s4));
+        CHECK(c.pref->contained(c.sz + 1));
+        const int n5 = (int)strlen(r_txt5);
+        seq_accessor s5(r_txt5, true, n5);
+        CHECK(c.pref->try_align(c.pal, 0, &s5));
+        c.pref->evolve();
+        CHECK((unsigned)n5 == c.pref->length());
+        CHECK(c.reads_forward(r_txt5, n5));
+    }
+    {   // prepend, :238-254
+        RefCase c;
+        const int n6 = (int)strlen(r_txt6), n7 = (int)strlen(r_txt7);
+        seq_accessor s6(r_txt6 + n6 - 1, false, n6);
+        CHECK(c.pref->try_align(c.pal, c.sz - 1, &s6));
+        CHECK(c.pref->contained(-1));
+        seq_accessor s7(r_txt7 + n7 - 1, false, n7);
+        CHECK(c.pref->try_align(c.pal, c.sz - 1, &s7));
+        c.pref->evolve();
+        CHECK((unsigned)n7 == c.pref->length());
+        CHECK(c.reads_backward(r_txt7, n7 - 1));
+    }
+}
+
 int main(int argc, char **argv) {
     dna_binary();
     accessor();
     aligner(argc > 1 ? argv[1] : "tests/golden/real_align.txt");
     ref_basic();
+    ref_unlocked();
     printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail ? 1 : 0;
 }

@@ -362,7 +362,8 @@ def test_fullsize_kernels_agree_and_recover_planted_loci(ctx):
 # ----------------------------------------------------------------------------- the reference's API surface
 def test_compat_headers_cpp(lib):
     """include/compat/{dna_seq,seq_aligner,ref_seq}.h: the reference's own test expectations (dna_test,
-    aligner_test scores, ref_test basic) compiled with g++ against the compat headers and run on the GPU."""
+    aligner_test incl. edit scripts, all twelve ref_test cases: votes, growth, evolve) compiled with g++ against the
+    compat headers and run on the GPU."""
     import os
     import subprocess
     from conftest import ROOT
