@@ -315,7 +315,9 @@ typedef struct {
     uint64_t n_candidates;         /* (target position, probe) matches */
     uint64_t n_pairs;              /* candidate pairs handed to the banded DP (stops at the first success per pair of reads) */
     uint64_t n_overlaps;           /* successful (target, query) pairs */
+    uint64_t n_redo;               /* (target, query) runs resumed at the reference band (narrow window not certified) */
     float scan_ms, sort_ms, walk_ms;
+    float pad_;
 } pba_overlap_stats;
 
 /* out: caller-allocated, cap entries; *n_out = overlaps found (may exceed cap: then only cap are written).

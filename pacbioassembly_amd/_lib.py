@@ -34,7 +34,8 @@ class PbaLocStats(C.Structure):
 
 class PbaOverlapStats(C.Structure):
     _fields_ = [("n_probe_entries", C.c_uint64), ("n_candidates", C.c_uint64), ("n_pairs", C.c_uint64),
-                ("n_overlaps", C.c_uint64), ("scan_ms", C.c_float), ("sort_ms", C.c_float), ("walk_ms", C.c_float)]
+                ("n_overlaps", C.c_uint64), ("n_redo", C.c_uint64), ("scan_ms", C.c_float), ("sort_ms", C.c_float),
+                ("walk_ms", C.c_float), ("pad_", C.c_float)]
 
 
 class PbaProfile(C.Structure):

@@ -219,19 +219,21 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     };
 
     // rare, divergent: segment finished last step / window opens now / window closed last step / diagonal enters
-#define PBA_BV_RARE()                                                                 \
+#define PBA_BV_RARE(ON_EVENT)                                                         \
     if (__builtin_amdgcn_ballot_w64(t == t_next)) {      /* wave-uniform: all lanes enabled for the shuffle */ \
       const int above = __shfl(score, (lane + PBA_WAVE - 1) & (PBA_WAVE - 1), PBA_WAVE); \
       if (t == t_next) {                                                              \
         if (t == t_seg + 1) segment_done(t, above);                                   \
         if (t == t_evt) {                                                             \
-            if (opened) { s_cur += PBA_WAVE; open_superblock(); }                     \
+            /* a lane that moves on to its next superblock needs that superblock's slice of the text; a lane that \
+               opens its first window already got its planes at the start of the chunk (no load, no wait: during  \
+               the ramp one lane opens per step, and false candidates are all ramp) */                              \
+            if (opened) { s_cur += PBA_WAVE; open_superblock(); load_text(t - ((t - 1) & 31)); } \
             if (t == t_evt) {                                                         \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; } \
                 opened = 1;                                                           \
                 t_evt = t_close1;                                                     \
             }                                                                         \
-            load_text(t - ((t - 1) & 31));                                            \
         }                                                                             \
         if (t == t_dstart) {                                                          \
             dmw = 1u; t_dstart = INT_MAX;                                             \
@@ -240,6 +242,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         t_next = min(min(t_evt, t_seg + 1), min(t_dstart, t <= t_hin_end ? t_hin_end + 1 : INT_MAX)); \
       }                                                                               \
       valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);   /* changes only at events: kept as a scalar mask */ \
+      ON_EVENT;                                                                       \
     }
 
     // hin of each lane's first block: the lane above's hout of the previous step, rotated one lane up, where that
@@ -282,12 +285,14 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     bool failed = false;
     for (int tbv = 1; tbv <= t1; tbv += 32) {
         const int tb = __builtin_amdgcn_readfirstlane(tbv);   // (the early exit below makes the compiler treat tbv as divergent)
-        load_text(tb);                           // next text planes; poll for failure
-        if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; break; }
-        const int kend = min(32, t1 - tb + 1);
+        load_text(tb);                           // next text planes
+        if (failed) break;
+        int kend = min(32, t1 - tb + 1);
         for (int k = 0; k < kend; ++k) {
         const int t = tb + k;
-        PBA_BV_RARE();
+        // a segment that just ended may have failed the reference's check: leave right after this step (false
+        // candidates die on their first segment, so they cost 33 steps, not the 64 of a poll per chunk)
+        PBA_BV_RARE(if (__builtin_amdgcn_ballot_w64(fail_row != 0)) { failed = true; kend = k; });
         const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
 #pragma unroll
@@ -328,7 +333,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         const int kend = min(32, k0 + (t_end - tb + 1));
         for (int k = k0; k < kend; ++k) {
         const int t = tb - k0 + k;
-        PBA_BV_RARE();
+        PBA_BV_RARE((void)0);
         const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
         uint32_t ph_m = 0, mh_m = 0;

@@ -13,7 +13,9 @@
 //                  candidate = query << 23 | (2j + backward) << 16 | ordinal   (count pass, then fill pass)
 //   (per-target sort of the candidates: k_part_sort; 64-bit order = query, then j, forward before backward,
 //    then the seedmap's list order -- exactly the order spaced_seed tries them in)
-//   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query
+//   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query;
+//                  (target, query) runs whose narrow-window verdict is not certified are parked and resumed by a
+//                  second launch at the reference band
 #ifndef PBA_OVERLAP_H
 #define PBA_OVERLAP_H
 
@@ -104,66 +106,95 @@ struct OvlCfg {
     uint32_t t2;
 };
 
-// NB1: blocks per lane of the narrow first pass, NB2: of the reference-band re-run taken in place when the
-// narrow pass cannot certify the goal row (NB1 = NB2 = 0: row sweep).
-template <int NB1, int NB2>
-__global__ void __launch_bounds__(PBA_WAVE * (NB1 ? 4 : 1), NB1 == 0 ? 1 : (NB2 <= 4 ? 5 : 3))
-k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
-           pba_overlap *out, unsigned long long cap, unsigned long long *n_out, unsigned long long *n_pairs,
-           uint32_t *queue) {
+// One candidate of target `ref` (length ref_len, visiting order ht): set up like spaced_seed.cpp:274-286 /
+// ref_seq.h:282-286 and align.  Returns false when the candidate is skipped before the aligner (too short).
+template <int NB>
+__device__ __forceinline__ bool ovl_candidate(const SeqSetDev &Rd, const uint8_t *ref, int ref_len, const HeadTail &ht,
+                                              uint64_t cd, const OvlCfg &cfg, bool full_band, uint16_t *lds, AlnOut &o,
+                                              int &j_out, bool &fwd_out, int &hit_out) {
+    const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
+    const uint32_t jd = (uint32_t)(cd >> PBA_OVL_ORD_BITS) & ((1u << PBA_OVL_JD_BITS) - 1);
+    const int hit = ht.pos_of((int)(cd & ((1u << PBA_OVL_ORD_BITS) - 1)));
+    const int slen = (int)Rd.len[q];
+    const int j = (int)(jd >> 1);
+    const bool fwd = (jd & 1) == 0;
+    const int pos = fwd ? j : slen - j - 16;
+    const int s_off = fwd ? pos : pos + 15;                     // spaced_seed.cpp:274
+    const int s_len = fwd ? slen - s_off : s_off + 1;           // spaced_seed.cpp:275
+    if (s_len < cfg.overlap_min) return false;                  // spaced_seed.cpp:280
+    const int r_off = fwd ? hit : hit + 15;                     // spaced_seed.cpp:285
+    const int r_len = fwd ? ref_len - r_off : r_off + 1;        // ref_seq.h:284-285
+    PackedFetch fa{ref, r_off, fwd ? 1 : -1};                   // a = the target in the reference role (ref_seq.h:264)
+    PackedFetch fb{Rd.packed + Rd.off[q], s_off, fwd ? 1 : -1};
+    if constexpr (NB == 0) align_rowsweep(fa, r_len, fb, s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
+    else align_bitvec<NB>(fa, r_len, fb, s_len, cfg.R, 0, 0, full_band, lds, cfg.row_cap, o);
+    j_out = j; fwd_out = fwd; hit_out = hit;
+    return true;
+}
+
+__device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long cap, unsigned long long *n_out, uint32_t t,
+                                         uint32_t q, int j, bool fwd, int hit, const AlnOut &o) {
+    // every lane calls the atomic (lane 0 adds 1): the lane-0-only form inside a persistent loop is what
+    // ROCm 7.2's clang miscompiles (tools/ubench_queue.hip)
+    const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
+    const unsigned long long slot = atomicAdd(n_out, l0 ? 1ull : 0ull);
+    if (l0 && slot < cap) {
+        pba_overlap *r = out + slot;
+        r->target = (int32_t)t; r->query = (int32_t)q; r->j = j; r->dir = fwd ? 1 : -1; r->ref_pos = hit;
+        r->cost = o.cost; r->matlen_a = o.matlen_a; r->matlen_b = o.matlen_b;
+    }
+}
+
+// First launch (redo_in == nullptr): persistent wavefronts pull targets and walk their candidates with the narrow
+// window (NB = 0: row sweep).  A candidate the narrow window cannot certify parks its (target, query): the rest of
+// that query's candidates are skipped and (target - t_lo, candidate index) goes to redo_out.
+// Second launch (redo_in != nullptr, full_band): one parked (target, query) per work item, resumed at the parked
+// candidate with the reference band until the first success or the end of the query's candidates.
+template <int NB>
+__global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 4 ? 6 : 3))
+k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
+           int full_band, const uint2 *redo_in, uint2 *redo_out, unsigned long long redo_cap,
+           unsigned long long *n_redo_out, pba_overlap *out, unsigned long long cap, unsigned long long *n_out,
+           unsigned long long *n_pairs, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
     uint16_t *lds = (uint16_t *)(lds_all + (size_t)wave * cfg.row_cap * 2);
+    const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
     for (;;) {
-        const uint32_t tl = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)atomicAdd(queue, (threadIdx.x & (PBA_WAVE - 1)) == 0 ? 1u : 0u));     // see next_slot() in pba_device.hip
-        if (tl >= n_targets) break;
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)atomicAdd(queue, l0 ? 1u : 0u));                       // see next_slot() in pba_device.hip
+        if (item >= n_items) break;
+        uint32_t tl, c_begin, c_end;
+        if (redo_in) { tl = redo_in[item].x; c_begin = redo_in[item].y; c_end = cand_off[tl + 1]; }
+        else { tl = item; c_begin = cand_off[tl]; c_end = cand_off[tl + 1]; }
         const uint32_t t = t_lo + tl;
         const uint8_t *ref = Rd.packed + Rd.off[t];
         const int ref_len = (int)Rd.len[t];
         const HeadTail ht(ref_len);
+        const uint32_t only_q = redo_in ? (uint32_t)(cand[c_begin] >> PBA_OVL_Q_SHIFT) : 0xFFFFFFFFu;
         uint32_t done_q = 0xFFFFFFFFu;
         unsigned long long pairs = 0;
-        for (uint32_t c = cand_off[tl]; c < cand_off[tl + 1]; ++c) {
+        for (uint32_t c = c_begin; c < c_end; ++c) {
             const uint64_t cd = cand[c];
             const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
+            if (redo_in && q != only_q) break;                          // the parked query's candidates are contiguous
             if (q == done_q) continue;                                  // first success per (target, query) already taken
-            const uint32_t jd = (uint32_t)(cd >> PBA_OVL_ORD_BITS) & ((1u << PBA_OVL_JD_BITS) - 1);
-            const int hit = ht.pos_of((int)(cd & ((1u << PBA_OVL_ORD_BITS) - 1)));
-            const int slen = (int)Rd.len[q];
-            const int j = (int)(jd >> 1);
-            const bool fwd = (jd & 1) == 0;
-            const int pos = fwd ? j : slen - j - 16;
-            const int s_off = fwd ? pos : pos + 15;                     // spaced_seed.cpp:274
-            const int s_len = fwd ? slen - s_off : s_off + 1;           // spaced_seed.cpp:275
-            if (s_len < cfg.overlap_min) continue;                      // spaced_seed.cpp:280
-            const int r_off = fwd ? hit : hit + 15;                     // spaced_seed.cpp:285
-            const int r_len = fwd ? ref_len - r_off : r_off + 1;        // ref_seq.h:284-285
-            PackedFetch fa{ref, r_off, fwd ? 1 : -1};                   // a = the target in the reference role (ref_seq.h:264)
-            PackedFetch fb{Rd.packed + Rd.off[q], s_off, fwd ? 1 : -1};
             AlnOut o;
-            if constexpr (NB1 == 0) {
-                align_rowsweep(fa, r_len, fb, s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
-            } else {
-                align_bitvec<NB1>(fa, r_len, fb, s_len, cfg.R, 0, 0, false, lds, cfg.row_cap, o);
-                if (o.rc == PBA_RC_UNCERTIFIED) align_bitvec<NB2>(fa, r_len, fb, s_len, cfg.R, 0, 0, true, lds, cfg.row_cap, o);
+            int j = 0, hit = 0;
+            bool fwd = true;
+            if (!ovl_candidate<NB>(Rd, ref, ref_len, ht, cd, cfg, full_band != 0, lds, o, j, fwd, hit)) continue;
+            if (o.rc == PBA_RC_UNCERTIFIED) {                           // only in the first launch
+                done_q = q;
+                const unsigned long long slot = atomicAdd(n_redo_out, l0 ? 1ull : 0ull);
+                if (l0 && slot < redo_cap) redo_out[slot] = make_uint2(tl, c);
+                continue;
             }
             ++pairs;
             if (o.rc < 0 || o.matlen_a < cfg.overlap_min) continue;     // ref_seq.h:264-265
             done_q = q;
-            // every lane calls the atomic (lane 0 adds 1): the lane-0-only form inside a persistent loop is what
-            // ROCm 7.2's clang miscompiles (tools/ubench_queue.hip)
-            const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
-            const unsigned long long slot = atomicAdd(n_out, l0 ? 1ull : 0ull);
-            if (l0) {
-                if (slot < cap) {
-                    pba_overlap *r = out + slot;
-                    r->target = (int32_t)t; r->query = (int32_t)q; r->j = j; r->dir = fwd ? 1 : -1; r->ref_pos = hit;
-                    r->cost = o.cost; r->matlen_a = o.matlen_a; r->matlen_b = o.matlen_b;
-                }
-            }
+            ovl_emit(out, cap, n_out, t, q, j, fwd, hit, o);
         }
-        atomicAdd(n_pairs, (threadIdx.x & (PBA_WAVE - 1)) == 0 ? pairs : 0ull);
+        atomicAdd(n_pairs, l0 ? pairs : 0ull);
     }
 }
 

@@ -1414,11 +1414,12 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
 // ---------------------------------------------------------------------------------------------
 // host API: all-vs-all overlap
 // ---------------------------------------------------------------------------------------------
-#define PBA_OVL_CASE(N1, N2)                                                                                          \
-    hipLaunchKernelGGL((k_ovl_walk<N1, N2>), dim3(persistent_grid(ctx, nt, (N1) ? 4 : 1, lds)),                        \
-                       dim3(PBA_WAVE * ((N1) ? 4 : 1)), lds * ((N1) ? 4 : 1), ctx->stream, reads->dev(), t_lo, nt,     \
-                       d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, d_out.as<pba_overlap>(),                     \
-                       (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1, \
+#define PBA_OVL_WALK(NBV)                                                                                             \
+    hipLaunchKernelGGL((k_ovl_walk<NBV>), dim3(persistent_grid(ctx, n_items, (NBV) ? 4 : 1, lds)),                        \
+                       dim3(PBA_WAVE * ((NBV) ? 4 : 1)), lds * ((NBV) ? 4 : 1), ctx->stream, reads->dev(), t_lo, n_items,  \
+                       d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, full_band, redo_in, d_redo.as<uint2>(),        \
+                       (unsigned long long)redo_cap, d_cnt64.as<unsigned long long>() + 2, d_out.as<pba_overlap>(),     \
+                       (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1,  \
                        ctx->d_queue)
 
 int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint32_t q_hi, uint32_t mask, int max_trial,
@@ -1483,7 +1484,7 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
 
     // 1. probe table: the (gathered) probe entries, partitioned and sorted like a seed index
     DevBuf d_cnt64;
-    HIPCHK(hipMalloc(&d_cnt64.p, 16));
+    HIPCHK(hipMalloc(&d_cnt64.p, 32));
     (void)hipEventRecord(ctx->ev[2], ctx->stream);
     pba_index *pix = nullptr;
     rc = pba_index_from_entries(ctx, d_probe_entries, n_probe_slots, mask, PBA_INDEX_ALL, 0, &pix);   // identity ordinal -> value: the probe id
@@ -1533,27 +1534,39 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     }
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
 
-    // 4. walk: persistent wavefronts, one target at a time
+    // 4. walk: persistent wavefronts, one target at a time, narrow window; then the parked (target, query) runs
+    //    at the reference band
     HIPCHK(hipMalloc(&d_out.p, sizeof(pba_overlap) * (cap + 1)));
-    HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 32, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
     OvlCfg ocfg;
     ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
     const size_t lds = pl.lds;
-    const int key = pl.nb1 * 10 + pl.nb2;
-    switch (key) {
-        case 0: PBA_OVL_CASE(0, 0); break;
-        case 11: PBA_OVL_CASE(1, 1); break;
-        case 12: PBA_OVL_CASE(1, 2); break;
-        case 13: PBA_OVL_CASE(1, 3); break;
-        case 23: PBA_OVL_CASE(2, 3); break;
-        case 24: PBA_OVL_CASE(2, 4); break;
-        case 26: PBA_OVL_CASE(2, 6); break;
-        case 36: PBA_OVL_CASE(3, 6); break;
-        case 38: PBA_OVL_CASE(3, 8); break;
-        case 48: PBA_OVL_CASE(4, 8); break;
-        default: PBA_OVL_CASE(8, 8); break;      // any pair with nb1 <= 8 and nb2 <= 8 is valid (NB only needs to be large enough)
+    DevBuf d_redo, d_redo2;
+    uint64_t redo_cap = std::max<uint64_t>(1024, total / 8);
+    HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2) * redo_cap));
+    {
+        const uint32_t n_items = nt;
+        const int full_band = 0;
+        const uint2 *redo_in = nullptr;
+        PBA_DISPATCH_NB(pl.nb1, PBA_OVL_WALK);
     }
+    HIPCHK(hipGetLastError());
+    unsigned long long h_redo = 0;
+    HIPCHK(hipMemcpyAsync(&h_redo, d_cnt64.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (h_redo > redo_cap) PBA_FAIL(PBA_E_NOMEM, "pba_overlap_all: more uncertified (target, query) runs than the redo list holds");
+    if (h_redo) {
+        d_redo2.p = d_redo.p; d_redo.p = nullptr;                // the list just written becomes the input
+        HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2)));             // (nothing is parked in the second launch)
+        HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
+        const uint32_t n_items = (uint32_t)h_redo;
+        const int full_band = 1;
+        const uint2 *redo_in = d_redo2.as<uint2>();
+        redo_cap = 1;
+        PBA_DISPATCH_NB(pl.nb2, PBA_OVL_WALK);
+    }
+    st.n_redo = h_redo;
     (void)hipEventRecord(ctx->ev[5], ctx->stream);
     HIPCHK(hipGetLastError());
     unsigned long long h_cnt2[2] = {0, 0};

@@ -610,6 +610,32 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     assert [tuple(int(x) for x in r) for r in got2] == want and st2["n_probe_entries"] == st["n_probe_entries"]
 
 
+def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):
+    """Reads at ~12 % error each overlap at ~24 % between them: the narrow window cannot certify most true overlaps, the
+    (target, query) run is parked and resumed at the reference band by the second launch -- and the answer is still
+    the oracle's composition, with the number of pairs aligned equal to the oracle's count."""
+    g = eng.synth_genome(81, 7000)
+    n, rl = 40, 1400
+    reads, offs, _ = eng.synth_reads(82, g, n, rl, 0.04, 0.04, 0.04)
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    want, pairs = [], 0
+    for t in range(n):
+        rows = oracle.spaced_round(texts[t], mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=8)
+        pairs += int(rows["n_pairs"].sum()) - int(rows["n_pairs"][t])
+        for q in range(n):
+            if q != t and rows["found"][q]:
+                want.append((t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]),
+                             int(rows["matlen_a"][q]), int(rows["matlen_b"][q])))
+    S = ctx.seqs_from_list(texts, strict_acgt=True)
+    got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_BITVEC)
+    assert [tuple(int(x) for x in r) for r in got] == want
+    assert len(want) > 60 and st["n_redo"] > 20
+    assert st["n_pairs"] == pairs
+
+
 # ----------------------------------------------------------------------------- consensus (ref_seq, unlocked)
 class GpuCons:
     """ref_seq::try_align (ref_seq.h:259-276) composed from the C ABI: align + edit script on the GPU, votes and
