@@ -317,7 +317,7 @@ typedef struct {
     uint64_t n_overlaps;           /* successful (target, query) pairs */
     uint64_t n_redo;               /* (target, query) runs resumed at the reference band (narrow window not certified) */
     float scan_ms, sort_ms, walk_ms;
-    float pad_;
+    uint32_t wide_first;           /* 1: a sample showed the narrow window rarely certifies, the rest went straight to the reference band */
 } pba_overlap_stats;
 
 /* out: caller-allocated, cap entries; *n_out = overlaps found (may exceed cap: then only cap are written).

@@ -30,9 +30,10 @@
 //   * a PASSING diagonal verdict is always exact (W >= U);  a FAILING one at row i is exact when
 //     floor(i*R) < 2*wl+2 (no unseen path back to the diagonal is cheap enough to change it);
 //   * the goal row is exact when its minimum is <= min(w, 2*wl+1).
-// Anything else answers "uncertified" and the pair is re-run with wl = w = max_dst, the reference's
-// own band, where the two bullets above apply directly.  Results are bit-identical to the reference
-// in all cases.  First pass: w = 9/16 max_dst, wl = w/2: 25 % fewer cells than a symmetric window and,
+// Anything else answers "uncertified" and the pair is re-run with w = max_dst, the reference's own
+// band, and wl = max_dst/2 + 1: every row's threshold floor(i*R) <= max_dst - 1 < 2*wl + 2 and every goal
+// minimum of a pair that passed its checks is <= max_dst - 1, so that sweep certifies everything.
+// Results are bit-identical to the reference in all cases.  First pass: w = 9/16 max_dst, wl = w/2: 25 % fewer cells than a symmetric window and,
 // more to the point, narrow enough for one block less per lane at BASELINE sizes.
 #ifndef PBA_ALIGN_BITVEC_H
 #define PBA_ALIGN_BITVEC_H
@@ -368,7 +369,9 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
 }
 
 // true when the bit-vector kernel can take a pair with this max_dst (else: row sweep)
-__device__ __host__ inline bool bitvec_supports(int max_dst) { return bv_nb_for(max_dst) != 0; }
+// window of the certifying ("full band") sweep
+__device__ __host__ inline int bv_full_wl(int md) { return md / 2 + 1 < md ? md / 2 + 1 : md; }
+__device__ __host__ inline bool bitvec_supports(int max_dst) { return bv_nb_for_span(bv_full_wl(max_dst) + max_dst) != 0; }
 // first-pass window for a given max_dst: w columns right of the diagonal, wl left of it
 __device__ __host__ inline int bv_first_w(int md) {
     const int w = (md / 2 > (int)((long long)md * PBA_BV_BAND_NUM / PBA_BV_BAND_DEN)
@@ -381,10 +384,10 @@ __device__ __host__ inline int bv_first_wl(int md) {
 }
 // the verdicts of a sweep over [i - wl, i + w] (header comment): a failure at row fr / a goal minimum `best`
 __device__ __forceinline__ bool bv_fail_certified(int fr, double R, int wl, int md) {
-    return wl >= md || (double)fr * R < (double)(2 * wl + 2);
+    return 2 * wl + 2 > md || (double)fr * R < (double)(2 * wl + 2);      // floor(i*R) <= md - 1 for every row
 }
 __device__ __forceinline__ bool bv_goal_certified(int best, int wl, int w, int md) {
-    return (w >= md && wl >= md) || (best <= w && best <= 2 * wl + 1);
+    return (w >= md && 2 * wl + 1 >= md) || (best <= w && best <= 2 * wl + 1);   // a passing pair has best <= md - 1
 }
 
 #define PBA_RC_UNCERTIFIED (-3)   // narrow pass could not certify the goal row: re-run with full_band
@@ -407,7 +410,7 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
         align_rowsweep(fa, la, fb, lb, R, maxn, maxm, lds, lds_cells, o);
         return;
     }
-    const int w = full_band ? md : bv_first_w(md), wl = full_band ? md : bv_first_wl(md);
+    const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
     if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
     const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
     int best = 0, bestj = 0;

@@ -130,7 +130,7 @@ __device__ __forceinline__ void align_bitvec_trace(const PackedFetch &fa, int la
         }
     } else {
         const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
-        const int w = full_band ? md : bv_first_w(md), wl = full_band ? md : bv_first_wl(md);
+        const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
         int best = 0, bestj = 0;
         if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes both
         const int fr = bitvec_pass<NB, true>(rowsF, m, colsF, n, wl, w, R, best, bestj, scratch, swap);

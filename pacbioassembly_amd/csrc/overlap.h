@@ -23,6 +23,7 @@
 #include "align_rowsweep.h"
 #include "dev_common.h"
 #include "pba.h"
+#include "prefilter.h"
 #include "seed_index.h"
 
 #define PBA_OVL_ORD_BITS 16
@@ -106,30 +107,29 @@ struct OvlCfg {
     uint32_t t2;
 };
 
-// One candidate of target `ref` (length ref_len, visiting order ht): set up like spaced_seed.cpp:274-286 /
-// ref_seq.h:282-286 and align.  Returns false when the candidate is skipped before the aligner (too short).
-template <int NB>
-__device__ __forceinline__ bool ovl_candidate(const SeqSetDev &Rd, const uint8_t *ref, int ref_len, const HeadTail &ht,
-                                              uint64_t cd, const OvlCfg &cfg, bool full_band, uint16_t *lds, AlnOut &o,
-                                              int &j_out, bool &fwd_out, int &hit_out) {
-    const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
+// One candidate of target `ref` (length ref_len, visiting order ht) set up like spaced_seed.cpp:274-286 /
+// ref_seq.h:282-286.  ok = false: skipped before the aligner (segment shorter than OVERLAP_MIN).
+struct OvlCand {
+    bool ok, fwd;
+    uint32_t q;
+    int j, hit, r_off, r_len, s_off, s_len;
+};
+__device__ __forceinline__ OvlCand ovl_decode(const SeqSetDev &Rd, int ref_len, const HeadTail &ht, uint64_t cd,
+                                              const OvlCfg &cfg) {
+    OvlCand c;
+    c.q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
     const uint32_t jd = (uint32_t)(cd >> PBA_OVL_ORD_BITS) & ((1u << PBA_OVL_JD_BITS) - 1);
-    const int hit = ht.pos_of((int)(cd & ((1u << PBA_OVL_ORD_BITS) - 1)));
-    const int slen = (int)Rd.len[q];
-    const int j = (int)(jd >> 1);
-    const bool fwd = (jd & 1) == 0;
-    const int pos = fwd ? j : slen - j - 16;
-    const int s_off = fwd ? pos : pos + 15;                     // spaced_seed.cpp:274
-    const int s_len = fwd ? slen - s_off : s_off + 1;           // spaced_seed.cpp:275
-    if (s_len < cfg.overlap_min) return false;                  // spaced_seed.cpp:280
-    const int r_off = fwd ? hit : hit + 15;                     // spaced_seed.cpp:285
-    const int r_len = fwd ? ref_len - r_off : r_off + 1;        // ref_seq.h:284-285
-    PackedFetch fa{ref, r_off, fwd ? 1 : -1};                   // a = the target in the reference role (ref_seq.h:264)
-    PackedFetch fb{Rd.packed + Rd.off[q], s_off, fwd ? 1 : -1};
-    if constexpr (NB == 0) align_rowsweep(fa, r_len, fb, s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
-    else align_bitvec<NB>(fa, r_len, fb, s_len, cfg.R, 0, 0, full_band, lds, cfg.row_cap, o);
-    j_out = j; fwd_out = fwd; hit_out = hit;
-    return true;
+    c.hit = ht.pos_of((int)(cd & ((1u << PBA_OVL_ORD_BITS) - 1)));
+    const int slen = (int)Rd.len[c.q];
+    c.j = (int)(jd >> 1);
+    c.fwd = (jd & 1) == 0;
+    const int pos = c.fwd ? c.j : slen - c.j - 16;
+    c.s_off = c.fwd ? pos : pos + 15;                           // spaced_seed.cpp:274
+    c.s_len = c.fwd ? slen - c.s_off : c.s_off + 1;             // spaced_seed.cpp:275
+    c.ok = c.s_len >= cfg.overlap_min;                          // spaced_seed.cpp:280
+    c.r_off = c.fwd ? c.hit : c.hit + 15;                       // spaced_seed.cpp:285
+    c.r_len = c.fwd ? ref_len - c.r_off : c.r_off + 1;          // ref_seq.h:284-285
+    return c;
 }
 
 __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long cap, unsigned long long *n_out, uint32_t t,
@@ -145,54 +145,94 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
     }
 }
 
-// First launch (redo_in == nullptr): persistent wavefronts pull targets and walk their candidates with the narrow
-// window (NB = 0: row sweep).  A candidate the narrow window cannot certify parks its (target, query): the rest of
-// that query's candidates are skipped and (target - t_lo, candidate index) goes to redo_out.
+// First launch (redo_in == nullptr): persistent wavefronts pull work items = (target, group of 64 consecutive
+// candidates) and walk them with the narrow window (NB = 0: row sweep).  Candidates of one (target, query) are
+// consecutive and must be tried in order, so a group owns the runs that START in it: it skips a leading run begun in
+// the previous group and follows its last run past its own end.  (Whole targets as work items left the chip idle at
+// the end: a target costs as much as its few true overlaps, which vary a lot.)
+// A candidate the narrow window cannot certify parks its (target, query): the rest of that query's candidates are
+// skipped and (target - t_lo, candidate index) goes to redo_out.
 // Second launch (redo_in != nullptr, full_band): one parked (target, query) per work item, resumed at the parked
 // candidate with the reference band until the first success or the end of the query's candidates.
 template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 4 ? 6 : 3))
-k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
-           int full_band, const uint2 *redo_in, uint2 *redo_out, unsigned long long redo_cap,
+k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off,
+           const uint64_t *cand, OvlCfg cfg, int full_band, const uint2 *redo_in, uint2 *redo_out, unsigned long long redo_cap,
            unsigned long long *n_redo_out, pba_overlap *out, unsigned long long cap, unsigned long long *n_out,
            unsigned long long *n_pairs, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
     uint16_t *lds = (uint16_t *)(lds_all + (size_t)wave * cfg.row_cap * 2);
     const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
+    const PreThresholds pre_t(cfg.R);
     for (;;) {
         const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(
             (int)atomicAdd(queue, l0 ? 1u : 0u));                       // see next_slot() in pba_device.hip
         if (item >= n_items) break;
-        uint32_t tl, c_begin, c_end;
-        if (redo_in) { tl = redo_in[item].x; c_begin = redo_in[item].y; c_end = cand_off[tl + 1]; }
-        else { tl = item; c_begin = cand_off[tl]; c_end = cand_off[tl + 1]; }
+        const uint32_t NONE = 0xFFFFFFFFu;
+        uint32_t tl, c_begin, c_end, own_end, skip_q = NONE, only_q = NONE;
+        if (redo_in) {
+            tl = redo_in[item].x; c_begin = redo_in[item].y; c_end = own_end = cand_off[tl + 1];
+            only_q = (uint32_t)(cand[c_begin] >> PBA_OVL_Q_SHIFT);
+        } else {
+            tl = items[item].x; c_begin = items[item].y; c_end = cand_off[tl + 1];
+            own_end = min(c_begin + (uint32_t)PBA_WAVE, c_end);
+            if (c_begin > cand_off[tl]) skip_q = (uint32_t)(cand[c_begin - 1] >> PBA_OVL_Q_SHIFT);   // a run begun in the previous group
+        }
         const uint32_t t = t_lo + tl;
         const uint8_t *ref = Rd.packed + Rd.off[t];
         const int ref_len = (int)Rd.len[t];
         const HeadTail ht(ref_len);
-        const uint32_t only_q = redo_in ? (uint32_t)(cand[c_begin] >> PBA_OVL_Q_SHIFT) : 0xFFFFFFFFu;
-        uint32_t done_q = 0xFFFFFFFFu;
+        uint32_t done_q = NONE, last_q = NONE;
         unsigned long long pairs = 0;
-        for (uint32_t c = c_begin; c < c_end; ++c) {
-            const uint64_t cd = cand[c];
-            const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
-            if (redo_in && q != only_q) break;                          // the parked query's candidates are contiguous
-            if (q == done_q) continue;                                  // first success per (target, query) already taken
-            AlnOut o;
-            int j = 0, hit = 0;
-            bool fwd = true;
-            if (!ovl_candidate<NB>(Rd, ref, ref_len, ht, cd, cfg, full_band != 0, lds, o, j, fwd, hit)) continue;
-            if (o.rc == PBA_RC_UNCERTIFIED) {                           // only in the first launch
-                done_q = q;
-                const unsigned long long slot = atomicAdd(n_redo_out, l0 ? 1ull : 0ull);
-                if (l0 && slot < redo_cap) redo_out[slot] = make_uint2(tl, c);
-                continue;
+        bool stop = false;
+        // 64 candidates at a time: every lane decodes its candidate and runs its first 32 rows (prefilter.h); then the
+        // group is walked in order and only the candidates that survived get the wavefront
+        for (uint32_t c0 = c_begin; c0 < c_end && !stop; c0 += PBA_WAVE) {
+            if (c0 >= own_end) {                                            // past the own group: only to finish its last run
+                const uint32_t nq = (uint32_t)(cand[c0] >> PBA_OVL_Q_SHIFT);
+                if (nq != last_q || done_q == last_q || skip_q == last_q) break;
             }
-            ++pairs;
-            if (o.rc < 0 || o.matlen_a < cfg.overlap_min) continue;     // ref_seq.h:264-265
-            done_q = q;
-            ovl_emit(out, cap, n_out, t, q, j, fwd, hit, o);
+            const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), ng = min((uint32_t)PBA_WAVE, c_end - c0);
+            const bool act = lane < ng;
+            const uint64_t mycd = act ? cand[c0 + lane] : 0ull;
+            int myfr = 0;
+            if constexpr (NB != 0) {
+                const OvlCand m = ovl_decode(Rd, ref_len, ht, mycd, cfg);
+                AlnOut po;
+                myfr = prefilter32(act && m.ok, PackedFetch{ref, m.r_off, m.fwd ? 1 : -1}, m.r_len,
+                                   PackedFetch{Rd.packed + Rd.off[act ? m.q : 0], m.s_off, m.fwd ? 1 : -1}, m.s_len, cfg.R, 0, 0,
+                                   pre_t, po);
+            }
+            for (uint32_t k = 0; k < ng; ++k) {
+                const uint32_t c = c0 + k;
+                const uint64_t cd = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mycd >> 32), (int)k) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)mycd, (int)k);
+                const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
+                if (redo_in && q != only_q) { stop = true; break; }         // the parked query's candidates are contiguous
+                if (c >= own_end && q != last_q) { stop = true; break; }    // the run that started in the own group has ended
+                last_q = q;
+                if (q == skip_q) continue;                                  // this run belongs to the previous group
+                if (q == done_q) continue;                                  // first success per (target, query) already taken
+                if (__builtin_amdgcn_readlane(myfr, (int)k)) { ++pairs; continue; }   // failed within its first 32 rows
+                const OvlCand m = ovl_decode(Rd, ref_len, ht, cd, cfg);
+                if (!m.ok) continue;
+                PackedFetch fa{ref, m.r_off, m.fwd ? 1 : -1};               // a = the target in the reference role (ref_seq.h:264)
+                PackedFetch fb{Rd.packed + Rd.off[q], m.s_off, m.fwd ? 1 : -1};
+                AlnOut o;
+                if constexpr (NB == 0) align_rowsweep(fa, m.r_len, fb, m.s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
+                else align_bitvec<NB>(fa, m.r_len, fb, m.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);
+                if (o.rc == PBA_RC_UNCERTIFIED) {                           // only in the first launch
+                    done_q = q;
+                    const unsigned long long slot = atomicAdd(n_redo_out, l0 ? 1ull : 0ull);
+                    if (l0 && slot < redo_cap) redo_out[slot] = make_uint2(tl, c);
+                    continue;
+                }
+                ++pairs;
+                if (o.rc < 0 || o.matlen_a < cfg.overlap_min) continue;     // ref_seq.h:264-265
+                done_q = q;
+                ovl_emit(out, cap, n_out, t, q, m.j, m.fwd, m.hit, o);
+            }
         }
         atomicAdd(n_pairs, l0 ? pairs : 0ull);
     }

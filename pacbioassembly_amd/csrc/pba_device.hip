@@ -19,6 +19,7 @@
 #include "dev_common.h"
 #include "pba.h"
 #include "pba_internal.h"
+#include "prefilter.h"
 #include "overlap.h"
 #include "seed_index.h"
 
@@ -309,6 +310,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    const PreThresholds pre_t(cfg.R);
     for (;;) {                                // persistent wavefront: pull the next read until the queue is dry
     const uint32_t slot = next_slot(queue);
     if (slot >= n) break;
@@ -327,18 +329,40 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
             ix_find(ix, key, beg, cnt);                                     // locator.cpp:76
             if (cnt == 0) continue;
             ++nhit;
-            for (uint32_t h = 0; h < cnt; ++h) {                            // locator.cpp:79
-                const int pos = ix_pos_of(ix, (uint32_t)ix.ent[beg + h]);
-                PackedFetch fa{rseq, j, 1};                                 // a = read from j   (locator.cpp:78)
-                PackedFetch fb{tsq, pos, 1};                                // b = contig from pos (locator.cpp:80)
-                AlnOut o;
-                align_dispatch<NB>(fa, len - j, fb, clen - pos, cfg, lds, o);
-                if (o.rc == PBA_RC_UNCERTIFIED) { redo = 1; break; }
-                ++npairs;
-                ncell += pair_cells(o);
-                if (o.rc > 0) {                                             // locator.cpp:82
-                    found = 1; fj = j; fpos = pos; fcost = o.cost; fma = o.matlen_a; fmb = o.matlen_b;
-                    break;
+            // locator.cpp:79, 64 hits at a time: every lane runs the first 32 rows of its hit (prefilter.h), then the
+            // hits are walked in list order -- the ones that failed there are done, the others get the wavefront
+            for (uint32_t h0 = 0; h0 < cnt && !found && !redo; h0 += PBA_WAVE) {
+                const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), ng = min((uint32_t)PBA_WAVE, cnt - h0);
+                const bool act = lane < ng;
+                const int mypos = act ? ix_pos_of(ix, (uint32_t)ix.ent[beg + h0 + lane]) : 0;
+                int myfr = 0;
+                long long mycells = 0;
+                if constexpr (NB != 0) {
+                    AlnOut po;
+                    myfr = prefilter32(act, PackedFetch{rseq, j, 1}, len - j, PackedFetch{tsq, mypos, 1}, clen - mypos, cfg.R,
+                                       cfg.maxn, cfg.maxm, pre_t, po);
+                    mycells = myfr ? band_cells(po.len_b, po.max_dst, myfr) : 0;
+                }
+                for (uint32_t hh = 0; hh < ng; ++hh) {
+                    const int fr = __builtin_amdgcn_readlane(myfr, (int)hh);
+                    if (fr) {                                               // failed at row fr <= 32: seq_aligner.h:185
+                        ++npairs;
+                        ncell += ((long long)__builtin_amdgcn_readlane((int)(mycells >> 32), (int)hh) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)mycells, (int)hh);
+                        continue;
+                    }
+                    const int pos = __builtin_amdgcn_readlane(mypos, (int)hh);
+                    PackedFetch fa{rseq, j, 1};                             // a = read from j   (locator.cpp:78)
+                    PackedFetch fb{tsq, pos, 1};                            // b = contig from pos (locator.cpp:80)
+                    AlnOut o;
+                    align_dispatch<NB>(fa, len - j, fb, clen - pos, cfg, lds, o);
+                    if (o.rc == PBA_RC_UNCERTIFIED) { redo = 1; break; }
+                    ++npairs;
+                    ncell += pair_cells(o);
+                    if (o.rc > 0) {                                         // locator.cpp:82
+                        found = 1; fj = j; fpos = pos; fcost = o.cost; fma = o.matlen_a; fmb = o.matlen_b;
+                        break;
+                    }
                 }
             }
         }
@@ -365,7 +389,7 @@ struct SsState {
 template <int NB>
 __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, int ref_len, const uint8_t *rseq,
                                        int slen, int pos, int dir, int overlap_min, int buggy, const AlignCfg &cfg,
-                                       void *lds, SsState &st) {
+                                       const PreThresholds &pre_t, void *lds, SsState &st) {
     if (pos < 0 || pos + 16 > slen) return false;   // the reference only keeps reads > 500 bases
     const uint32_t key = seed_at_dev(rseq, pos, (uint32_t)slen, buggy) & ix.mask;   // spaced_seed.cpp:265
     if (key == 0) return false;
@@ -377,20 +401,33 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, i
     const int s_off = fwd ? pos : pos + 15;                        // spaced_seed.cpp:274
     const int s_len = fwd ? slen - s_off : s_off + 1;              // spaced_seed.cpp:275
     if (s_len < overlap_min) return false;                         // spaced_seed.cpp:280
-    for (uint32_t h = 0; h < cnt; ++h) {
-        const int hit = ix_pos_of(ix, (uint32_t)ix.ent[beg + h]);
-        const int r_off = fwd ? hit : hit + 15;                    // spaced_seed.cpp:285
-        const int r_len = fwd ? ref_len - r_off : r_off + 1;       // ref_seq.h:284-285
-        PackedFetch fa{ref, r_off, fwd ? 1 : -1};                  // a = reference (ref_seq.h:264)
-        PackedFetch fb{rseq, s_off, fwd ? 1 : -1};
-        AlnOut o;
-        align_dispatch<NB>(fa, r_len, fb, s_len, cfg, lds, o);
-        if (o.rc == PBA_RC_UNCERTIFIED) { st.redo = 1; return true; }
-        ++st.npairs;
-        if (o.rc < 0) continue;                                    // ref_seq.h:264
-        if (o.matlen_a < overlap_min) continue;                    // ref_seq.h:265
-        st.found = 1; st.dir = dir; st.ref_pos = hit; st.cost = o.cost; st.ma = o.matlen_a; st.mb = o.matlen_b;
-        return true;
+    for (uint32_t h0 = 0; h0 < cnt; h0 += PBA_WAVE) {                 // 64 hits at a time through the prefilter, then in list order
+        const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), ng = min((uint32_t)PBA_WAVE, cnt - h0);
+        const bool act = lane < ng;
+        const int myhit = act ? ix_pos_of(ix, (uint32_t)ix.ent[beg + h0 + lane]) : 0;
+        int myfr = 0;
+        if constexpr (NB != 0) {
+            const int r_off = fwd ? myhit : myhit + 15;
+            AlnOut po;
+            myfr = prefilter32(act, PackedFetch{ref, r_off, fwd ? 1 : -1}, fwd ? ref_len - r_off : r_off + 1,
+                               PackedFetch{rseq, s_off, fwd ? 1 : -1}, s_len, cfg.R, cfg.maxn, cfg.maxm, pre_t, po);
+        }
+        for (uint32_t hh = 0; hh < ng; ++hh) {
+            if (__builtin_amdgcn_readlane(myfr, (int)hh)) { ++st.npairs; continue; }   // failed within its first 32 rows
+            const int hit = __builtin_amdgcn_readlane(myhit, (int)hh);
+            const int r_off = fwd ? hit : hit + 15;                    // spaced_seed.cpp:285
+            const int r_len = fwd ? ref_len - r_off : r_off + 1;       // ref_seq.h:284-285
+            PackedFetch fa{ref, r_off, fwd ? 1 : -1};                  // a = reference (ref_seq.h:264)
+            PackedFetch fb{rseq, s_off, fwd ? 1 : -1};
+            AlnOut o;
+            align_dispatch<NB>(fa, r_len, fb, s_len, cfg, lds, o);
+            if (o.rc == PBA_RC_UNCERTIFIED) { st.redo = 1; return true; }
+            ++st.npairs;
+            if (o.rc < 0) continue;                                    // ref_seq.h:264
+            if (o.matlen_a < overlap_min) continue;                    // ref_seq.h:265
+            st.found = 1; st.dir = dir; st.ref_pos = hit; st.cost = o.cost; st.ma = o.matlen_a; st.mb = o.matlen_b;
+            return true;
+        }
     }
     return false;
 }
@@ -402,6 +439,7 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const 
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    const PreThresholds pre_t(cfg.R);
     for (;;) {
     const uint32_t slot = next_slot(queue);
     if (slot >= n) break;
@@ -413,8 +451,8 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const 
     SsState st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int fj = -1;
     for (int j = 0; j < max_trial; ++j) {                          // spaced_seed.cpp:424-426
-        if (ss_try<NB>(ix, ref, ref_len, rseq, slen, j, 1, overlap_min, buggy, cfg, lds, st) ||
-            ss_try<NB>(ix, ref, ref_len, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, lds, st)) {
+        if (ss_try<NB>(ix, ref, ref_len, rseq, slen, j, 1, overlap_min, buggy, cfg, pre_t, lds, st) ||
+            ss_try<NB>(ix, ref, ref_len, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, pre_t, lds, st)) {
             fj = j;
             break;
         }
@@ -985,7 +1023,7 @@ static int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int
     pl->cfg.row_cap = (int)(bytes / 2);
     pl->lds = (size_t)bytes;
     pl->nb1 = bv ? bv_nb_for_span(bv_first_wl(max_dst_max) + bv_first_w(max_dst_max)) : 0;
-    pl->nb2 = bv ? bv_nb_for(max_dst_max) : 0;
+    pl->nb2 = bv ? bv_nb_for_span(bv_full_wl(max_dst_max) + max_dst_max) : 0;
     return PBA_OK;
 }
 
@@ -1417,7 +1455,8 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
 #define PBA_OVL_WALK(NBV)                                                                                             \
     hipLaunchKernelGGL((k_ovl_walk<NBV>), dim3(persistent_grid(ctx, n_items, (NBV) ? 4 : 1, lds)),                        \
                        dim3(PBA_WAVE * ((NBV) ? 4 : 1)), lds * ((NBV) ? 4 : 1), ctx->stream, reads->dev(), t_lo, n_items,  \
-                       d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, full_band, redo_in, d_redo.as<uint2>(),        \
+                       items, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, full_band, redo_in,                     \
+                       d_redo.as<uint2>(),                                                                              \
                        (unsigned long long)redo_cap, d_cnt64.as<unsigned long long>() + 2, d_out.as<pba_overlap>(),     \
                        (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1,  \
                        ctx->d_queue)
@@ -1542,31 +1581,68 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     OvlCfg ocfg;
     ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
     const size_t lds = pl.lds;
-    DevBuf d_redo, d_redo2;
-    uint64_t redo_cap = std::max<uint64_t>(1024, total / 8);
+    DevBuf d_redo, d_items;
+    const uint64_t redo_cap = std::max<uint64_t>(1024, total / 4);
     HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2) * redo_cap));
-    {
-        const uint32_t n_items = nt;
-        const int full_band = 0;
-        const uint2 *redo_in = nullptr;
-        PBA_DISPATCH_NB(pl.nb1, PBA_OVL_WALK);
-    }
-    HIPCHK(hipGetLastError());
-    unsigned long long h_redo = 0;
-    HIPCHK(hipMemcpyAsync(&h_redo, d_cnt64.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (h_redo > redo_cap) PBA_FAIL(PBA_E_NOMEM, "pba_overlap_all: more uncertified (target, query) runs than the redo list holds");
-    if (h_redo) {
-        d_redo2.p = d_redo.p; d_redo.p = nullptr;                // the list just written becomes the input
-        HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2)));             // (nothing is parked in the second launch)
+    std::vector<uint2> h_items;                                  // work items: (target, first candidate of a group of 64)
+    h_items.reserve((size_t)(total / PBA_WAVE) + nt);
+    for (uint32_t i = 0; i < nt; ++i)
+        for (uint32_t c = h_off[i]; c < h_off[i] + h_cnt[i]; c += PBA_WAVE) h_items.push_back(make_uint2(i, c));
+    HIPCHK(hipMalloc(&d_items.p, sizeof(uint2) * (h_items.size() + 1)));
+    if (!h_items.empty())
+        HIPCHK(hipMemcpyAsync(d_items.p, h_items.data(), sizeof(uint2) * h_items.size(), hipMemcpyHostToDevice, ctx->stream));
+    // one launch of the walk: items [lo, hi) of the group list (redo_in == nullptr) or n_redo parked runs
+    auto walk = [&](int nb, const uint2 *items, uint32_t n_items, int full_band, const uint2 *redo_in) -> int {
         HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
-        const uint32_t n_items = (uint32_t)h_redo;
-        const int full_band = 1;
-        const uint2 *redo_in = d_redo2.as<uint2>();
-        redo_cap = 1;
-        PBA_DISPATCH_NB(pl.nb2, PBA_OVL_WALK);
+        HIPCHK(hipMemsetAsync(d_cnt64.as<unsigned long long>() + 2, 0, 8, ctx->stream));
+        PBA_DISPATCH_NB(nb, PBA_OVL_WALK);
+        HIPCHK(hipGetLastError());
+        return PBA_OK;
+    };
+    // narrow window for items [lo, hi), then the runs it parked at the reference band; returns the number parked
+    uint64_t parked_total = 0;
+    auto narrow_then_redo = [&](size_t lo, size_t hi, uint64_t *parked) -> int {
+        *parked = 0;
+        if (hi <= lo) return PBA_OK;
+        int rc2 = walk(pl.nb1, d_items.as<uint2>() + lo, (uint32_t)(hi - lo), 0, nullptr);
+        if (rc2 != PBA_OK) return rc2;
+        unsigned long long h_redo = 0;
+        HIPCHK(hipMemcpyAsync(&h_redo, d_cnt64.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (h_redo > redo_cap) PBA_FAIL(PBA_E_NOMEM, "pba_overlap_all: more uncertified (target, query) runs than the redo list holds");
+        *parked = h_redo;
+        if (!h_redo) return PBA_OK;
+        DevBuf d_in;
+        HIPCHK(hipMalloc(&d_in.p, sizeof(uint2) * h_redo));
+        HIPCHK(hipMemcpyAsync(d_in.p, d_redo.p, sizeof(uint2) * h_redo, hipMemcpyDeviceToDevice, ctx->stream));
+        rc2 = walk(pl.nb2, nullptr, (uint32_t)h_redo, 1, d_in.as<uint2>());
+        if (rc2 != PBA_OK) return rc2;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return PBA_OK;
+    };
+    // Whether the narrow window pays depends on how far the reads are from each other (two 15 % reads differ by ~27 %:
+    // nothing certifies below the reference band), which only the data tells: a sample of the items goes through
+    // narrow-then-redo, and if most of its successful runs had to be parked the rest goes straight to the reference band.
+    const size_t n_all = h_items.size();
+    const size_t n_sample = pl.nb1 == 0 ? n_all : std::min(n_all, std::max<size_t>(4096, n_all / 32));
+    uint64_t parked = 0;
+    rc = narrow_then_redo(0, n_sample, &parked);
+    if (rc != PBA_OK) return rc;
+    parked_total += parked;
+    if (n_sample < n_all) {
+        unsigned long long h_ov = 0;
+        HIPCHK(hipMemcpyAsync(&h_ov, d_cnt64.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (2 * parked > h_ov) {                                 // most overlaps of the sample needed the reference band
+            rc = walk(pl.nb2, d_items.as<uint2>() + n_sample, (uint32_t)(n_all - n_sample), 1, nullptr);
+            st.wide_first = 1;
+        } else {
+            rc = narrow_then_redo(n_sample, n_all, &parked);
+            parked_total += parked;
+        }
+        if (rc != PBA_OK) return rc;
     }
-    st.n_redo = h_redo;
+    st.n_redo = parked_total;
     (void)hipEventRecord(ctx->ev[5], ctx->stream);
     HIPCHK(hipGetLastError());
     unsigned long long h_cnt2[2] = {0, 0};

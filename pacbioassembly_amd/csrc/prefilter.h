@@ -1,0 +1,63 @@
+// prefilter.h -- the first 32 rows of seq_aligner<>::align for 64 candidate pairs at once, ONE PAIR PER LANE.
+//
+// Most candidates a seed lookup returns are false hits, and the reference's sweep throws them out at one of its
+// first diagonal checks (cost(i,i) > i*R for i > 10, /root/reference/src/seq_aligner.h:185): a random pair fails by
+// row ~11-20.  The cell (i,i) depends only on the square [1..i] x [1..i], and on that square the banded matrix and
+// the plain edit-distance matrix U decide the check identically (point 1: a path that passes the check
+// cannot afford to leave the band).  So one 32-row Myers block per lane, swept over the first 32 columns, gives the
+// reference's verdict for rows 11..32 exactly: the first failing row if there is one.  Pairs that survive go to the
+// wavefront-wide aligner as before; pairs that fail here never get a wavefront.
+// ~16 lane-ops per column instead of a 64-lane array stepping through its ramp: a false candidate costs ~10
+// wave-instructions instead of several thousand.
+#ifndef PBA_PREFILTER_H
+#define PBA_PREFILTER_H
+
+#include "align_bitvec.h"
+#include "dev_common.h"
+
+#define PBA_PRE_ROWS 32
+
+// floor(i * R) for i = 0..32, FP64 exactly as the reference forms i*R; an integer d satisfies
+// (double)d > (double)i*R  <=>  d > floor((double)i*R)
+struct PreThresholds {
+    int t[PBA_PRE_ROWS + 1];
+    __device__ __forceinline__ explicit PreThresholds(double R) {
+#pragma unroll
+        for (int i = 0; i <= PBA_PRE_ROWS; ++i) t[i] = __builtin_amdgcn_readfirstlane((int)floor((double)i * R));
+    }
+};
+
+// Returns the first failing row (11..32) of the pair this LANE holds, or 0 when rows 11..32 all pass or the
+// prefilter does not apply (a sequence shorter than 32 after the reference's length clipping, the size guard) --
+// then the full aligner decides.  `active`: lanes without a pair must pass false (they return 0).
+__device__ __forceinline__ int prefilter32(bool active, const PackedFetch &fa, int la, const PackedFetch &fb, int lb,
+                                           double R, int maxn, int maxm, const PreThresholds &T, AlnOut &o) {
+    aln_params(la, lb, R, o);
+    if (!active) return 0;
+    if (maxn > 0 && (o.len_a >= maxn + maxm || o.max_dst >= maxm)) return 0;   // seq_aligner.h:104-107: the caller's path
+    if (o.len_a < PBA_PRE_ROWS || o.len_b < PBA_PRE_ROWS) return 0;
+    uint32_t alo, ahi, blo, bhi;
+    load_planes32(fa, 0, alo, ahi);            // rows: a[0..31]
+    load_planes32(fb, 0, blo, bhi);            // columns: b[0..31], bit k = column k+1
+    uint32_t Pv = ~0u, Mv = 0u;                // column 0: D(i,0) = i
+    int score = 0, fr = 0;                     // score = D(j,j)
+#pragma unroll
+    for (int k = 0; k < PBA_PRE_ROWS; ++k) {
+        const uint32_t clo = bit_mask(blo, k), chi = bit_mask(bhi, k);
+        const uint32_t Eq = ~(alo ^ clo) & ~(ahi ^ chi);
+        const uint32_t Xv = Eq | Mv;
+        const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+        uint32_t Ph = Mv | ~(Xh | Pv);
+        uint32_t Mh = Pv & Xh;
+        const uint32_t D0 = Xh | Mv;           // bit r: D(r+1, k+1) == D(r, k)
+        score += 1 - (int)((D0 >> k) & 1u);    // D(k+1, k+1) = D(k, k) + (the diagonal cell's D0 ? 0 : 1)
+        Ph = (Ph << 1) | 1u;                   // row 0 grows by one per column: D(0,j) = j
+        Mh <<= 1;
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+        if (k + 1 > 10 && fr == 0 && score > T.t[k + 1]) fr = k + 1;
+    }
+    return fr;
+}
+
+#endif
