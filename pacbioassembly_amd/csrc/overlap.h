@@ -60,11 +60,24 @@ struct HeadTail {
     __device__ __forceinline__ int pos_of(int ord) const { return ord < nhead ? ord : tail_top - (ord - nhead); }
 };
 
+// Presence filter of the probe table: one bit per hashed key (2^26 bits = 8 MB, L2 / MALL resident).  Only ~1 in 13
+// positions of a target carries a key some probe has (2*max_trial probes per read against 4^12 keys), so one bit
+// load spares the scan most of its dependent binary searches.
+#define PBA_OVL_PRES_LOG 26
+__device__ __forceinline__ uint32_t ovl_pres_slot(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - PBA_OVL_PRES_LOG); }
+__global__ void __launch_bounds__(256)
+k_ovl_presence(const uint64_t *ent, uint64_t n, uint32_t *bits) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = ovl_pres_slot((uint32_t)(ent[i] >> 32));
+    atomicOr(bits + (h >> 5), 1u << (h & 31));
+}
+
 // FILL = false: cnt[t - t_lo] = candidates of target t.  FILL = true: write them at cursor[t - t_lo]++.
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_ovl_scan(IndexDev probes, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2, uint32_t *cnt_or_cursor,
-           uint64_t *cand) {
+k_ovl_scan(IndexDev probes, const uint32_t *presence, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2,
+           uint32_t *cnt_or_cursor, uint64_t *cand) {
     const uint32_t tl = blockIdx.x;
     if (tl >= n_targets) return;
     const uint32_t t = t_lo + tl;
@@ -76,6 +89,8 @@ k_ovl_scan(IndexDev probes, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uin
         const int pos = ht.pos_of(ord);
         const uint32_t key = window_key(seq, (uint32_t)pos, (uint32_t)len) & probes.mask;
         if (!key) continue;                                             // ref_seq.h:300,307
+        const uint32_t h = ovl_pres_slot(key);
+        if (!((presence[h >> 5] >> (h & 31)) & 1u)) continue;           // no probe has this key
         uint32_t beg, n;
         ix_find(probes, key, beg, n);
         for (uint32_t h = 0; h < n; ++h) {

@@ -1532,11 +1532,16 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     st.n_probe_entries = pix->n_entries;
 
     // 2. scan the targets' positions against the probe table: count, offsets, fill
-    DevBuf d_off, d_cur, d_cand, d_out;
+    DevBuf d_off, d_cur, d_cand, d_out, d_pres;
+    HIPCHK(hipMalloc(&d_pres.p, (size_t)1 << (PBA_OVL_PRES_LOG - 3)));
+    HIPCHK(hipMemsetAsync(d_pres.p, 0, (size_t)1 << (PBA_OVL_PRES_LOG - 3), ctx->stream));
+    if (pix->n_entries)
+        hipLaunchKernelGGL(k_ovl_presence, dim3((uint32_t)((pix->n_entries + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)pix->d_ent, (uint64_t)pix->n_entries, d_pres.as<uint32_t>());
     HIPCHK(hipMalloc(&d_off.p, sizeof(uint32_t) * (nt + 1)));
     HIPCHK(hipMalloc(&d_cur.p, sizeof(uint32_t) * (nt + 1)));
-    hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), reads->dev(), t_lo, nt, t2,
-                       d_cur.as<uint32_t>(), (uint64_t *)nullptr);
+    hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), d_pres.as<uint32_t>(), reads->dev(),
+                       t_lo, nt, t2, d_cur.as<uint32_t>(), (uint64_t *)nullptr);
     std::vector<uint32_t> h_cnt(nt + 1), h_off(nt + 1);
     HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cur.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1550,8 +1555,8 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_cur.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
     if (total) {
-        hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), reads->dev(), t_lo, nt, t2,
-                           d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
+        hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), d_pres.as<uint32_t>(),
+                           reads->dev(), t_lo, nt, t2, d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
         (void)hipEventRecord(ctx->ev[3], ctx->stream);
         // 3. per-target sort = the reference's try order inside every (target, query)
         uint32_t biggest = 2;
