@@ -705,3 +705,17 @@ def test_consensus_golden_and_oracle(ctx, oracle):
     for x, y in zip(one.dump()[:3], many.dump()[:3]):
         assert (x == y).all()
     assert one.evolve() == many.evolve()
+
+
+def test_kernels_agree_on_drifting_paths():
+    """tools/stress_kernels.py (indel-biased pairs whose optimal path drifts towards the window edges, error rates up to
+    the acceptance limit, tails, all direction combinations): the full-band row sweep and the bit-vector array with its
+    prefilter, asymmetric windows and certificates agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_kernels.py"), "--batches", "3", "--pairs", "200",
+                        "--max-len", "6000", "--seed", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("same=True") == 3
