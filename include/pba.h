@@ -296,6 +296,22 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
                      const pba_seqs *reads, double R, int max_trial, int overlap_min, int buggy_seed_at,
                      int kernel, pba_ss_row *rows);
 
+/* spaced_seed's main loop (spaced_seed.cpp:409-452) for a LOCKED reference (-l; the reference never changes, so a
+ * round is pba_spaced_round over the reads not found yet): the seed of a round is masks[picks[k] % n_masks] for the
+ * k-th draw (picks[] stands in for rand(), spaced_seed.cpp:412) after a round that found something, else the seeds in
+ * order; found reads leave the pool; the loop ends after max_round rounds or when every seed failed in a row.
+ * rows[r] = the row of the round that found read r (found = 0: its last failed round), found_round[r] = that round
+ * (1-based) or 0; log[k] describes round k+1 (up to log_cap), *n_rounds = rounds run. */
+typedef struct {
+    int32_t round;
+    uint32_t mask;
+    int32_t n_tried, n_found;
+} pba_ss_round_log;
+int pba_spaced_multi(pba_ctx *ctx, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads, double ratio, int max_trial,
+                     int overlap_min, int buggy_seed_at, int kernel, const uint32_t *masks, int n_masks,
+                     const uint32_t *picks, int n_picks, int max_round, pba_ss_row *rows, int32_t *found_round,
+                     pba_ss_round_log *log, int log_cap, int *n_rounds);
+
 /* ------------------------------------------------------------------------ */
 /* All-vs-all overlap.  Not a loop the reference  */
 /* has, but built only from its pieces: every read t in [t_lo, t_hi) takes the */

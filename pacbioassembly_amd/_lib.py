@@ -97,6 +97,8 @@ SYMBOLS = {
     "pba_locate": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              _P, _P]),
     "pba_spaced_round": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "pba_spaced_multi": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int,
+                                   C.c_int, _P, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "pba_overlap_all": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, _P,
                                   C.c_uint64, C.POINTER(C.c_uint64), _P]),
     "pba_overlap_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

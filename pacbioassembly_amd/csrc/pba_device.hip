@@ -1391,8 +1391,11 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     return PBA_OK;
 }
 
-int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads,
-                     double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel, pba_ss_row *rows) {
+// One locked round over the reads `subset` (host ids; nullptr = every read).  rows is indexed by read id: rows of
+// reads outside the subset are left untouched.
+static int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads,
+                               double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel,
+                               const uint32_t *subset, uint32_t n_subset, pba_ss_row *rows) {
     if (!ctx || !ix || !ref || !reads || !rows || ref_seq >= ref->n || max_trial < 0) return PBA_E_INVALID;
     if (ix->mode != PBA_INDEX_HEAD_TAIL || ix->seq_len != ref->h_len[ref_seq])
         PBA_FAIL(PBA_E_INVALID, "pba_spaced_round needs a PBA_INDEX_HEAD_TAIL index of the reference sequence");
@@ -1400,24 +1403,30 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
         PBA_FAIL(PBA_E_TOOLONG, "sequence longer than the engine limit");
     if (ref->non_acgt || reads->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "pba_spaced_round: a sequence set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
-    const uint32_t n = reads->n;
+    const uint32_t n = reads->n, n_first = subset ? n_subset : n;
     Plan pl;
     // a = reference window, b = read window: the shorter side bounds max_dst (seq_aligner.h:94-102)
     int st = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (st != PBA_OK) return st;
-    DevBuf d_rows, d_redo, d_ids;
+    DevBuf d_rows, d_redo, d_ids, d_sub;
     HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_ss_row) * (n + 1)));
     HIPCHK(hipMalloc(&d_redo.p, sizeof(int) * (n + 1)));
+    HIPCHK(hipMemsetAsync(d_redo.p, 0, sizeof(int) * (n + 1), ctx->stream));
+    if (subset && n_subset) {
+        HIPCHK(hipMalloc(&d_sub.p, sizeof(uint32_t) * n_subset));
+        HIPCHK(hipMemcpyAsync(d_sub.p, subset, sizeof(uint32_t) * n_subset, hipMemcpyHostToDevice, ctx->stream));
+    }
 #define K_SS(NBV)                                                                                                    \
     (void)hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream);                                                           \
     hipLaunchKernelGGL(k_spaced_round<NBV>, dim3(persistent_grid(ctx, cnt, Wpb<NBV>::v, pl.lds)),                     \
                        dim3(PBA_WAVE * Wpb<NBV>::v), pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), ref->dev(),       \
                        ref_seq, reads->dev(), ids, cnt, max_trial, overlap_min, buggy_seed_at, pl.cfg,               \
                        d_rows.as<pba_ss_row>(), d_redo.as<int>(), ctx->d_queue)
-    if (n) {
+    if (n_first) {
         std::vector<int> h_redo(n);
-        const uint32_t cnt = n;
-        const uint32_t *ids = nullptr;
+        std::vector<pba_ss_row> h_rows(n);
+        const uint32_t cnt = n_first;
+        const uint32_t *ids = subset ? d_sub.as<uint32_t>() : nullptr;
         (void)hipEventRecord(ctx->ev[2], ctx->stream);
         PBA_DISPATCH_NB(pl.nb1, K_SS);
         (void)hipEventRecord(ctx->ev[3], ctx->stream);
@@ -1441,11 +1450,58 @@ int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uin
             ctx->prof.nb_redo = (uint32_t)pl.nb2; ctx->prof.n_redo = cnt;
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipMemcpyAsync(rows, d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h_rows.data(), d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!subset) memcpy(rows, h_rows.data(), sizeof(pba_ss_row) * n);
+        else for (uint32_t k = 0; k < n_subset; ++k) rows[subset[k]] = h_rows[subset[k]];
+        prof_finish(ctx);
     }
 #undef K_SS
-    if (n) prof_finish(ctx);
+    return PBA_OK;
+}
+
+int pba_spaced_round(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads,
+                     double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel, pba_ss_row *rows) {
+    return spaced_round_subset(ctx, ix, ref, ref_seq, reads, R, max_trial, overlap_min, buggy_seed_at, kernel, nullptr, 0, rows);
+}
+
+// spaced_seed.cpp:409-452 for a locked reference (-l): rounds over the reads not found yet, the seed of a round drawn
+// like the reference draws it (a fresh draw after a round that found something, else the seeds in file order), stop
+// when every seed has failed in a row or after max_round.  picks[] stands in for the values rand() returns.
+int pba_spaced_multi(pba_ctx *ctx, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads, double R, int max_trial,
+                     int overlap_min, int buggy_seed_at, int kernel, const uint32_t *masks, int n_masks,
+                     const uint32_t *picks, int n_picks, int max_round, pba_ss_row *rows, int32_t *found_round,
+                     pba_ss_round_log *log, int log_cap, int *n_rounds) {
+    if (!ctx || !ref || !reads || !masks || n_masks < 1 || !picks || n_picks < 1 || max_round < 0 || !rows || !found_round ||
+        !n_rounds || log_cap < 0 || (!log && log_cap) || ref_seq >= ref->n)
+        return PBA_E_INVALID;
+    const uint32_t n = reads->n;
+    std::vector<uint32_t> pool(n);
+    for (uint32_t r = 0; r < n; ++r) { pool[r] = r; found_round[r] = 0; memset(&rows[r], 0, sizeof rows[r]); rows[r].read = (int32_t)r; rows[r].j = -1; }
+    int nfailure = 0, draws = 0, done = 0;
+    for (int nround = 1; nround <= max_round; ++nround) {
+        const uint32_t mask = nfailure == 0 ? masks[picks[draws++ % n_picks] % (uint32_t)n_masks] : masks[nfailure - 1];   // :412
+        pba_index *ix = nullptr;
+        int st = pba_index_build(ctx, ref, ref_seq, mask, PBA_INDEX_HEAD_TAIL, &ix);        // get_seedmap, :415
+        if (st != PBA_OK) return st;
+        st = spaced_round_subset(ctx, ix, ref, ref_seq, reads, R, max_trial, overlap_min, buggy_seed_at, kernel, pool.data(),
+                                 (uint32_t)pool.size(), rows);
+        pba_index_destroy(ix);
+        if (st != PBA_OK) return st;
+        int nmatches = 0;
+        std::vector<uint32_t> rest;
+        rest.reserve(pool.size());
+        for (uint32_t r : pool) {
+            if (rows[r].found) { found_round[r] = nround; ++nmatches; }                     // erased from the pool, :443
+            else rest.push_back(r);
+        }
+        if (done < log_cap) { log[done].round = nround; log[done].mask = mask; log[done].n_tried = (int32_t)pool.size(); log[done].n_found = nmatches; }
+        ++done;
+        pool.swap(rest);
+        if (nmatches != 0) nfailure = 0;                                                    // :448-451
+        else if (++nfailure == n_masks) break;
+    }
+    *n_rounds = done;
     return PBA_OK;
 }
 

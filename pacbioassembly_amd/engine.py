@@ -270,6 +270,24 @@ class Context:
         return rows[:reads.count]
 
 
+def _spaced_multi(self, ref, ref_seq, reads, R, masks, picks, max_round=100, max_trial=32, overlap_min=64,
+                  buggy_seed_at=False, kernel=PBA_KERNEL_AUTO):
+    """spaced_seed's main loop for a locked reference; returns (rows, found_round, log list of dicts)."""
+    n = max(reads.count, 1)
+    rows = np.zeros(n, SS_ROW_DTYPE)
+    fr = np.zeros(n, np.int32)
+    log = np.zeros(max(max_round, 1), np.dtype([("round", "<i4"), ("mask", "<u4"), ("n_tried", "<i4"), ("n_found", "<i4")]))
+    masks = np.ascontiguousarray(masks, np.uint32); picks = np.ascontiguousarray(picks, np.uint32)
+    nr = C.c_int()
+    self.check(self.lib.pba_spaced_multi(self.h, ref.h, ref_seq, reads.h, R, max_trial, overlap_min, int(buggy_seed_at), kernel,
+                                         _ptr(masks), masks.size, _ptr(picks), picks.size, max_round, _ptr(rows), _ptr(fr),
+                                         _ptr(log), log.size, C.byref(nr)), "spaced_multi")
+    return rows[:reads.count], fr[:reads.count], [dict(zip(log.dtype.names, (int(x) for x in l))) for l in log[:nr.value]]
+
+
+Context.spaced_multi = _spaced_multi
+
+
 def _overlap_all(self, reads, mask, R, max_trial=32, overlap_min=64, t_lo=0, t_hi=None, kernel=PBA_KERNEL_AUTO,
                  cap=None):
     """All-vs-all overlap of a read set (targets t_lo..t_hi); returns (overlaps sorted by (target, query), stats)."""

@@ -75,3 +75,59 @@ def run_scenario(cons, reads, R=0.3):
         after = {"extent": ext, "votes": votes_digest(sel, sup, tot), "text": cons.text().decode()}
         rec["rounds"].append({"tries": rows, "before_evolve": before, "after_evolve": after})
     return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# spaced_seed's main loop for a locked reference (spaced_seed.cpp:409-452), composed from single locked rounds
+MULTI = dict(genome_seed=31, genome_len=30000, reads_seed=32, n_reads=160, read_len=1200, foreign_seed=33, n_foreign=24,
+             R=0.30, max_trial=3, overlap_min=64, max_round=40,
+             picks=[5, 2, 7, 7, 0, 3, 6, 1, 4, 2, 2, 5, 0, 7, 3, 1, 6, 4, 5, 5, 3, 0, 2, 6, 1, 7, 4])
+
+
+def multi_inputs():
+    """Reference text, the binary read file (reads of the reference plus reads of a foreign genome that never align),
+    record offsets."""
+    m = MULTI
+    g = eng.synth_genome(m["genome_seed"], m["genome_len"])
+    reads, offs, _ = eng.synth_reads(m["reads_seed"], g, m["n_reads"], m["read_len"])
+    f = eng.synth_genome(m["foreign_seed"], 20000)
+    fr, fo, _ = eng.synth_reads(m["foreign_seed"] + 1, f, m["n_foreign"], m["read_len"])
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(m["n_reads"])]
+    texts += [fr[int(fo[i]):int(fo[i + 1])].tobytes() for i in range(m["n_foreign"])]
+    order = np.random.RandomState(7).permutation(len(texts))
+    texts = [texts[i] for i in order]
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    return g.tobytes(), file, rec_offs
+
+
+def multi_rounds(round_fn, masks, n_reads):
+    """The loop of spaced_seed.cpp:409-452 over round_fn(mask, pool) -> rows (one per pool entry, `found` column).
+    Returns (found_round per read, log [[round, mask, tried, found], ...], rows of the finding round per read)."""
+    m = MULTI
+    pool = list(range(n_reads))
+    found_round = [0] * n_reads
+    final = [None] * n_reads
+    log, nfailure, draws = [], 0, 0
+    for nround in range(1, m["max_round"] + 1):
+        if nfailure == 0:
+            mask = masks[m["picks"][draws % len(m["picks"])] % len(masks)]; draws += 1
+        else:
+            mask = masks[nfailure - 1]
+        rows = round_fn(mask, pool)
+        nm, rest = 0, []
+        for k, r in enumerate(pool):
+            final[r] = [int(rows[c][k]) for c in ("found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")]
+            if rows["found"][k]:
+                found_round[r] = nround; nm += 1
+            else:
+                rest.append(r)
+        log.append([nround, int(mask), len(pool), nm])
+        pool = rest
+        if nm:
+            nfailure = 0
+        else:
+            nfailure += 1
+            if nfailure == len(masks):
+                break
+    return found_round, log, final

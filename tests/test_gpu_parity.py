@@ -719,3 +719,22 @@ def test_kernels_agree_on_drifting_paths():
                         "--max-len", "6000", "--seed", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("same=True") == 3
+
+
+def test_spaced_multi_golden(ctx):
+    """pba_spaced_multi (spaced_seed.cpp:409-452 for a locked reference) against the chain of the reference's own
+    locked rounds (tests/golden/spaced_multi.json): same seed per round, same reads found per round, same rows."""
+    from cons_scenarios import MULTI, multi_inputs
+    gold = gold_json("spaced_multi.json")
+    text, file, rec_offs = multi_inputs()
+    Rf = ctx.seqs_from_list([text])
+    Rd = ctx.seqs_from_records(file, 0, 1 << 30)
+    assert Rd.count == rec_offs.size
+    rows, fr, log = ctx.spaced_multi(Rf, 0, Rd, MULTI["R"], gold["masks"], MULTI["picks"], MULTI["max_round"], MULTI["max_trial"],
+                                     MULTI["overlap_min"], buggy_seed_at=True)
+    assert [[l["round"], l["mask"], l["n_tried"], l["n_found"]] for l in log] == gold["log"]
+    assert fr.tolist() == gold["found_round"]
+    for r, want in enumerate(gold["final"]):
+        assert int(rows["found"][r]) == want[0]
+        if want[0]:
+            assert [int(rows[c][r]) for c in ("found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")] == want, r

@@ -167,3 +167,18 @@ def test_consensus_golden(oracle):
             assert a["before_evolve"] == b["before_evolve"], (sc[0], k)
             assert a["after_evolve"] == b["after_evolve"], (sc[0], k)
         assert sum(t[4] for r in want["rounds"] for t in r["tries"]) >= 12
+
+
+def test_spaced_multi_golden(oracle):
+    """spaced_seed's main loop for a locked reference (seed rotation, pool erasure, stop rule; spaced_seed.cpp:409-452):
+    the oracle's locked rounds chained by the same loop reproduce the reference's chain."""
+    from cons_scenarios import MULTI, multi_inputs, multi_rounds
+    gold = gold_json("spaced_multi.json")
+    text, file, rec_offs = multi_inputs()
+    fn = lambda mask, pool: oracle.spaced_round(text, mask, MULTI["R"], file, rec_offs[pool], MULTI["max_trial"],
+                                                MULTI["overlap_min"], buggy=True, nthreads=4)
+    found_round, log, final = multi_rounds(fn, gold["masks"], rec_offs.size)
+    assert log == gold["log"] and found_round == gold["found_round"]
+    for r, (a, b) in enumerate(zip(final, gold["final"])):
+        assert a[0] == b[0] and (not a[0] or a == b), r
+    assert sum(1 for x in found_round if x) > 100 and len({x for x in found_round}) >= 5
