@@ -1729,7 +1729,7 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
 // host API: consensus voting and reference growth (ref_seq.h, the unlocked half)
 // ---------------------------------------------------------------------------------------------
 struct pba_cons {
-    pba_ctx *ctx;
+    int device;                           // (not the ctx: the object may outlive it, like pba_seqs / pba_index)
     int max_len, beg, end, pre, post;     // as in ref_seq (ref_seq.h:364-368), indices into the 3*max_len arrays
     int cur;                              // which of the two array sets is live (evolve ping-pongs)
     ConsDev set[2];
@@ -1766,7 +1766,7 @@ int pba_cons_create(pba_ctx *ctx, const char *text, int len, int weight, int max
     pba_cons *c = new (std::nothrow) pba_cons();
     if (!c) return PBA_E_NOMEM;
     memset(c, 0, sizeof *c);
-    c->ctx = ctx; c->max_len = max_len;
+    c->device = ctx->device; c->max_len = max_len;
     c->beg = c->pre = max_len; c->end = c->post = max_len + len;
     const size_t cap = (size_t)3 * max_len + 64;
     bool ok = hipMalloc((void **)&c->d_n, sizeof(int)) == hipSuccess;
@@ -1782,9 +1782,8 @@ int pba_cons_create(pba_ctx *ctx, const char *text, int len, int weight, int max
 
 void pba_cons_destroy(pba_cons *c) {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
-    cons_free_sets(c);
+    (void)hipSetDevice(c->device);
+    cons_free_sets(c);                    // hipFree waits for the work that uses the buffers
     delete c;
 }
 

@@ -738,3 +738,54 @@ def test_spaced_multi_golden(ctx):
         assert int(rows["found"][r]) == want[0]
         if want[0]:
             assert [int(rows[c][r]) for c in ("found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")] == want, r
+
+
+def test_edge_cases_of_the_widened_entry_points(ctx, oracle):
+    """Empty / degenerate inputs of the traceback, consensus, multi-round and overlap entry points: defined answers or
+    status codes, never a crash."""
+    S = ctx.seqs_from_list([b"ACGT" * 50, b"ACGTTGCA" * 20, b"", b"A"])
+    # empty batch, empty sequences, single bases through the trace kernels
+    out, scripts = ctx.align_batch_trace(S, S, np.zeros(0, PAIR_DTYPE), 0.3)
+    assert out.size == 0 and scripts == []
+    pairs = np.array([(2, 0, 0, 2, 0, 0, 0), (3, 0, 1, 3, 0, 1, 0), (2, 0, 0, 3, 0, 1, 0), (0, 0, 200, 0, 0, 200, 0)], PAIR_DTYPE)
+    for kernel in KERNELS:
+        out, scripts = ctx.align_batch_trace(S, S, pairs, 0.3, kernel=kernel)
+        for pr, got, ops in zip(pairs, out, scripts):
+            a = S.get_text(int(pr["a_seq"]))[:int(pr["a_len"])]; b = S.get_text(int(pr["b_seq"]))[:int(pr["b_len"])]
+            exp = oracle.align(a, b, 0.3, want_ops=True)
+            check_result(got, exp, (tuple(pr), kernel))
+            assert ops.tolist() == exp["ops"].tolist(), (tuple(pr), kernel)
+    with pytest.raises(PbaError) as e:                      # ops_off must leave a_len + b_len slots: checked, not trusted
+        off = np.array([0, 10], np.uint64); ne = np.zeros(1, np.int32); o = np.zeros(1, eng.RESULT_DTYPE); ops = np.zeros(16, np.uint8)
+        pr = np.array([(0, 0, 200, 0, 0, 200, 0)], PAIR_DTYPE)
+        ctx.check(ctx.lib.pba_align_batch_trace(ctx.h, S.h, S.h, pr.ctypes.data, 1, 0.3, 0, 0, 0, o.ctypes.data, ops.ctypes.data,
+                                                off.ctypes.data, ne.ctypes.data), "trace")
+    assert e.value.status == -1
+    # consensus: an empty reference, votes outside it, evolve of nothing
+    c = eng.Consensus(ctx, b"", 1, max_len=1000)
+    assert c.extent() == [0, 0, 0] and c.text() == b"" and c.evolve() == b""
+    c.append(b"ACGT")
+    assert c.text() == b"ACGT" and c.extent() == [0, 4, 0]
+    with pytest.raises(PbaError) as e:
+        c.elect([7], [True], [np.array([1], np.uint8)], [b"A"])      # "pos should be contained" (ref_seq.h:351)
+    assert e.value.status == -1
+    with pytest.raises(PbaError) as e:
+        eng.Consensus(ctx, b"ACGT" * 10, 1, max_len=8)               # longer than max_len
+    assert e.value.status == -1
+    c2 = eng.Consensus(ctx, b"ACGT", 1, max_len=4)
+    with pytest.raises(PbaError) as e:
+        c2.prepend(b"ACGTA")                                         # would grow past the buffer before the origin
+    assert e.value.status == -4
+    # votes that delete everything: evolve leaves an empty reference (every box invalid, nothing before the first to absorb)
+    c3 = eng.Consensus(ctx, b"ACGT", 1, max_len=100)
+    for _ in range(3):
+        c3.elect([0], [True], [np.array([3, 3, 3, 3], np.uint8)], [b"\\0\\0\\0\\0"])
+    assert c3.evolve() == b"" and c3.extent() == [0, 0, 0]
+    # multi-round driver with nothing to do, overlap of a single read
+    T = ctx.seqs_from_list([b"ACGT" * 200])
+    empty = ctx.seqs_from_list([])
+    rows, fr, log = ctx.spaced_multi(T, 0, empty, 0.3, [0xFFCCF3FC], [0], 5)
+    assert rows.size == 0 and fr.size == 0 and len(log) == 1 and log[0]["n_tried"] == 0     # one round, no match, one seed: stop
+    one = ctx.seqs_from_list([b"ACGT" * 300])
+    ov, st = ctx.overlap_all(one, 0xFFCCF3FC, 0.3, 8, 64)
+    assert ov.size == 0 and st["n_overlaps"] == 0
