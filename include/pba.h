@@ -247,6 +247,13 @@ int pba_cons_prepend(pba_ctx *ctx, pba_cons *c, const char *seg, int len);
  * edits[k].val (the b element of a MATCH / INSERT, seq_aligner.h:218,224). */
 int pba_cons_elect(pba_ctx *ctx, pba_cons *c, uint32_t n, const int32_t *pos, const uint8_t *fwd, const uint8_t *ops,
                    const char *vals, const uint64_t *ops_off, const int32_t *nedit);
+/* The batch form of try_align's align + OVERLAP_MIN gate + elect (ref_seq.h:264-267), everything on the device: pair q
+ * aligns a = A[ref_seq] from pairs[q].a_pos (the reference text of these boxes, as the caller uploaded it) against its
+ * b, and if it succeeds with matlen_a >= overlap_min the path is voted straight from the traceback walk -- no edit
+ * script leaves the GPU.  Both accessors of a pair run in the same direction.  No growth: append / prepend stay the
+ * caller's (a round of interior reads).  out[q] as pba_align_batch returns it. */
+int pba_cons_vote_pairs(pba_ctx *ctx, pba_cons *c, const pba_seqs *A, uint32_t ref_seq, const pba_seqs *B,
+                        const pba_pair *pairs, size_t n, double R, int maxn, int maxm, int overlap_min, pba_result *out);
 /* ref_seq::evolve (ref_seq.h:317-349): votes -> next reference; the boxes keep their counts, the new text
  * (new_len characters, up to cap copied) starts at beg and pre = beg, post = end = beg + new_len. */
 int pba_cons_evolve(pba_ctx *ctx, pba_cons *c, char *text_out, int cap, int32_t *new_len);

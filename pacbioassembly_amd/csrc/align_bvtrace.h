@@ -45,27 +45,36 @@ __device__ __forceinline__ uint32_t ld_coherent_u8(const uint8_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// ops leave the walk goal-first, 64 at a time: lane (k & 63) keeps op k until the group is full
+// A sink receives the path goal-first: put(op, i, j) = the reference's op at cell (i, j) of ITS matrix (a along i).
+// Everything passed to put() is wave-uniform.
+
+// ops into memory: 64 at a time (lane (k & 63) keeps op k until the group is full), goal-first into a temporary,
+// copied out reversed by finish()
 struct OpSink {
     uint8_t *tmp;
     int k;
     uint32_t pend;
-    __device__ __forceinline__ void put(int op) {        // op is wave-uniform
+    __device__ __forceinline__ void put(int op, int, int) {
         const int lane = threadIdx.x & (PBA_WAVE - 1);
         if (lane == (k & (PBA_WAVE - 1))) pend = (uint32_t)op;
         ++k;
         if ((k & (PBA_WAVE - 1)) == 0) tmp[k - PBA_WAVE + lane] = (uint8_t)pend;
     }
-    __device__ __forceinline__ void flush() {
+    // ops_out receives min(k, ops_cap) ops in the reference's order (origin first); returns nedit
+    __device__ __forceinline__ int finish(uint8_t *ops_out, uint64_t ops_cap) {
         const int lane = threadIdx.x & (PBA_WAVE - 1);
         if (lane < (k & (PBA_WAVE - 1))) tmp[(k & ~(PBA_WAVE - 1)) + lane] = (uint8_t)pend;
+        wave_mem_fence();
+        for (int x = lane; x < k; x += PBA_WAVE)
+            if ((uint64_t)x < ops_cap) ops_out[x] = (uint8_t)ld_coherent_u8(tmp + (k - 1 - x));
+        return k;
     }
 };
 
 // (ri, cj): the goal cell in array coordinates (rows = the shorter sequence).  Returns with the ops of the path
 // down to a border cell in `sink`; ri / cj hold that border cell.
-template <int NB>
-__device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &cj, bool swap_roles, OpSink &sink) {
+template <int NB, class Sink>
+__device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &cj, bool swap_roles, Sink &sink) {
     constexpr int RB = 32 * NB;
     const int lane = threadIdx.x & (PBA_WAVE - 1);
     while (ri > 0 && cj > 0) {
@@ -83,10 +92,11 @@ __device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &
             const int bit = (ri - 1) & 31;
             const uint32_t mbit = ((uint32_t)__builtin_amdgcn_readlane((int)wm, d) >> bit) & 1u;
             const uint32_t hbit = ((uint32_t)__builtin_amdgcn_readlane((int)wh, d) >> bit) & 1u;
+            const int oi = swap_roles ? cj : ri, oj = swap_roles ? ri : cj;   // the cell in the reference's coordinates
             if (mbit) {                                    // MATCH: (i-1, j-1)
-                sink.put(1); --ri; --cj; ++d;
+                sink.put(1, oi, oj); --ri; --cj; ++d;
             } else {
-                sink.put(hbit ? 2 : 3);                    // INSERT : DELETE
+                sink.put(hbit ? 2 : 3, oi, oj);            // INSERT : DELETE
                 if ((hbit != 0) != swap_roles) { --cj; ++d; }   // the array's column moves
                 else --ri;                                      // the array's row moves (same step, next bit down)
             }
@@ -94,69 +104,66 @@ __device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &
     }
 }
 
-// One pair with its edit script.  full_band = false sweeps the narrow first-pass window and answers
-// PBA_RC_UNCERTIFIED (no script) when its verdict cannot be certified; the host re-launches those pairs with
-// full_band = true (the reference band), like the score-only kernels do.
-// scratch: cap_words u32 of this wavefront's own; tmp: >= la + lb + 64 bytes of this wavefront's own.
-// ops_out receives min(nedit, ops_cap) ops in the reference's order (origin first); nedit = 0 unless o.rc >= 0.
-template <int NB>
-__device__ __forceinline__ void align_bitvec_trace(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
+// One pair with its path.  full_band = false sweeps the narrow first-pass window and answers PBA_RC_UNCERTIFIED
+// (nothing reaches the sink) when its verdict cannot be certified; the host re-launches those pairs with
+// full_band = true, like the score-only kernels do.  min_matlen_a: the path is walked only when
+// matlen_a >= min_matlen_a (ref_seq::try_align's OVERLAP_MIN gate, ref_seq.h:265; 0 for plain scripts).
+// scratch: cap_words u32 of this wavefront's own.  Returns true when the path went to the sink.
+template <int NB, class Sink>
+__device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
                                                    int maxn, int maxm, bool full_band, uint16_t *lds, int lds_cells,
-                                                   uint32_t *scratch, uint64_t cap_words, uint8_t *tmp, uint8_t *ops_out,
-                                                   uint64_t ops_cap, AlnOut &o, int &nedit) {
-    const int lane = threadIdx.x & (PBA_WAVE - 1);
-    nedit = 0;
+                                                   uint32_t *scratch, uint64_t cap_words, int min_matlen_a, Sink &sink,
+                                                   AlnOut &o) {
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
-    if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return;      // seq_aligner.h:104-107
+    if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return false;      // seq_aligner.h:104-107
     const bool swap = len_a > len_b;
     const int m = swap ? len_b : len_a, n = swap ? len_a : len_b;
-    OpSink sink{tmp, 0, 0u};
     if (m <= 10) {
         // the row sweep's corner (align_bitvec.h): one parent code per band cell in the scratch area
         const int W = 2 * md + 1;
-        if ((uint64_t)(len_a + 1) * (uint64_t)W > cap_words * 4) { o.rc = -2; return; }
+        if ((uint64_t)(len_a + 1) * (uint64_t)W > cap_words * 4) { o.rc = -2; return false; }
         uint8_t *par = (uint8_t *)scratch;
         align_rowsweep(fa, la, fb, lb, R, maxn, maxm, lds, lds_cells, o, par);
-        if (o.rc < 0) return;
+        if (o.rc < 0 || o.matlen_a < min_matlen_a) return false;
         wave_mem_fence();
         int i = o.matlen_a, j = o.matlen_b;
         while (i > 0 || j > 0) {
             // init_cell: (i,0) has parent DELETE, (0,j) INSERT (seq_aligner.h:140-147)
             const int src = j == 0 ? 3 : (i == 0 ? 2 : (int)ld_coherent_u8(par + (size_t)i * W + (j - i + md)));
             const int u = __builtin_amdgcn_readfirstlane(src);
-            sink.put(u);
+            sink.put(u, i, j);
             if (u == 1) { --i; --j; } else if (u == 2) --j; else --i;
         }
-    } else {
-        const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
-        const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
-        int best = 0, bestj = 0;
-        if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes both
-        const int fr = bitvec_pass<NB, true>(rowsF, m, colsF, n, wl, w, R, best, bestj, scratch, swap);
-        if (fr) {
-            if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
-            return;
-        }
-        if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return; }
-        o.cost = best;
-        o.matlen_a = swap ? bestj : m;
-        o.matlen_b = swap ? m : bestj;
-        o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114
-        if (o.rc < 0) return;
-        wave_mem_fence();                                   // the walk reads what other lanes stored
-        int ri = m, cj = bestj;
-        bv_trace_walk<NB>(scratch, ri, cj, swap, sink);
-        // border cells: the array's row 0 is the reference's i = 0 (INSERT) unless the roles are swapped
-        for (; ri > 0; --ri) sink.put(swap ? 2 : 3);
-        for (; cj > 0; --cj) sink.put(swap ? 3 : 2);
+        return true;
     }
-    sink.flush();
-    wave_mem_fence();
-    const int k = sink.k;
-    for (int x = lane; x < k; x += PBA_WAVE)
-        if ((uint64_t)x < ops_cap) ops_out[x] = (uint8_t)ld_coherent_u8(tmp + (k - 1 - x));
-    nedit = k;
+    const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
+    const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
+    int best = 0, bestj = 0;
+    if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return false; }   // host sizes both
+    const int fr = bitvec_pass<NB, true>(rowsF, m, colsF, n, wl, w, R, best, bestj, scratch, swap);
+    if (fr) {
+        if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
+        return false;
+    }
+    if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return false; }
+    o.cost = best;
+    o.matlen_a = swap ? bestj : m;
+    o.matlen_b = swap ? m : bestj;
+    o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114
+    if (o.rc < 0 || o.matlen_a < min_matlen_a) return false;
+    wave_mem_fence();                                   // the walk reads what other lanes stored
+    int ri = m, cj = bestj;
+    bv_trace_walk<NB>(scratch, ri, cj, swap, sink);
+    // border cells (init_cell): row 0 of the reference's matrix is INSERTs, column 0 DELETEs
+    if (swap) {
+        for (; ri > 0; --ri) sink.put(2, 0, ri);        // array rows are the reference's j
+        for (; cj > 0; --cj) sink.put(3, cj, 0);
+    } else {
+        for (; ri > 0; --ri) sink.put(3, ri, 0);
+        for (; cj > 0; --cj) sink.put(2, 0, cj);
+    }
+    return true;
 }
 
 #endif

@@ -78,6 +78,40 @@ k_cons_elect(ConsDev C, int beg, int pre, int post, uint32_t n, const int *pos, 
     }
 }
 
+// Votes straight from the traceback walk (align_bvtrace.h), no script in memory: a sink that turns the reference's
+// op at cell (i, j) into its vote.  The cell says it all: a MATCH / DELETE at (i, j) consumes a-element i-1, i.e. the
+// box `it0 +/- (i-1)`; an INSERT at (i, j) comes after i consumed elements, i.e. supplies box `it0 + i - 1` forward
+// (`--it; supply; ++it`) or `it0 - i` backward (apply_edits, ref_seq.h:25-41); the value is b-element j-1.
+// 64 votes are gathered (one per lane) and applied together, each lane fetching its own b element.
+struct VoteSink {
+    ConsDev C;
+    int it0, pre, post;         // box of the start position; the live range of boxes
+    bool fwd;
+    PackedFetch fb;             // the segment (b)
+    int k;
+    int p_at, p_j;              // this lane's pending vote: box, b element + 1 (0: none)
+    uint32_t p_op;
+    __device__ __forceinline__ void apply() {
+        if (p_op && p_at >= pre && p_at < post) {
+            if (p_op == 3) atomicAdd(C.tot + p_at, 1);                                  // ignore
+            else {
+                const int c = fb(p_j - 1);                                              // 2-bit code == C2I of the base
+                if (p_op == 1) { cons_bump(C.sel + p_at, c, 1u); atomicAdd(C.tot + p_at, 1); }   // select
+                else cons_bump(C.sup + p_at, c, 1u);                                    // supply
+            }
+        }
+        p_op = 0;
+    }
+    __device__ __forceinline__ void put(int op, int i, int j) {
+        const int lane = threadIdx.x & (PBA_WAVE - 1);
+        const int at = op == 2 ? (fwd ? it0 + i - 1 : it0 - i) : (fwd ? it0 + (i - 1) : it0 - (i - 1));
+        if (lane == (k & (PBA_WAVE - 1))) { p_op = (uint32_t)op; p_at = at; p_j = j; }
+        ++k;
+        if ((k & (PBA_WAVE - 1)) == 0) apply();
+    }
+    __device__ __forceinline__ void finish() { apply(); }
+};
+
 // evolve: [pre, post) of `in` -> boxes and text from index `beg` of `out`; *n_out = boxes kept
 __global__ void __launch_bounds__(1024)
 k_cons_evolve(ConsDev in, ConsDev out, int pre, int post, int beg, int *n_out) {

@@ -253,10 +253,41 @@ k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *i
         AlnOut o;
         int ne = 0;
         const uint64_t o0 = ops_off[q], o1 = ops_off[q + 1];
-        align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
-                               cfg.row_cap, mine, cap_words, (uint8_t *)(mine + cap_words), ops + o0, o1 - o0, o, ne);
+        OpSink sink{(uint8_t *)(mine + cap_words), 0, 0u};
+        if (align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
+                                   cfg.row_cap, mine, cap_words, 0, sink, o))
+            ne = sink.finish(ops + o0, o1 - o0);
         store_result(out + q, o);
         if ((threadIdx.x & (PBA_WAVE - 1)) == 0) nedit[q] = ne;
+    }
+}
+
+// The same sweep and walk, but the path goes straight into the vote boxes of an unlocked reference (consensus.h:
+// VoteSink) -- ref_seq::try_align's align + OVERLAP_MIN gate + elect (ref_seq.h:264-267) for a batch, no script in
+// memory.  a is the reference: pair.a_pos is the position the votes start at.
+template <int NB>
+__global__ void __launch_bounds__(PBA_WAVE * 4, NB <= 4 ? 4 : 2)
+k_vote_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg, int overlap_min,
+             pba_result *out, uint32_t *scratch, uint64_t wave_words, uint64_t cap_words, ConsDev C, int beg, int pre, int post,
+             uint32_t *queue) {
+    extern __shared__ __align__(16) uint8_t lds_all[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
+    uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
+    uint32_t *mine = scratch + ((uint64_t)blockIdx.x * 4 + wave) * wave_words;
+    for (;;) {
+        const uint32_t slot = next_slot(queue);
+        if (slot >= n) break;
+        const uint32_t q = ids ? ids[slot] : slot;
+        const pba_pair pr = pairs[q];
+        const bool fwd = !(pr.flags & PBA_A_BACKWARD);
+        PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, fwd ? 1 : -1};
+        PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+        AlnOut o;
+        VoteSink sink{C, beg + pr.a_pos, pre, post, fwd, fb, 0, 0, 0, 0u};
+        if (align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
+                                   cfg.row_cap, mine, cap_words, overlap_min, sink, o))
+            sink.finish();
+        store_result(out + q, o);
     }
 }
 
@@ -1195,10 +1226,15 @@ static uint64_t trace_words_of(int la, int lb, double R, int nb, bool full_band)
     return bv_trace_words(nb, m, n, full_band ? md : bv_first_w(md));
 }
 
-int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
-                          int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
-                          int32_t *nedit) {
-    if (!ctx || !A || !B || (!pairs && n) || (!out && n) || (!ops_off && n) || (!nedit && n)) return PBA_E_INVALID;
+struct pba_cons;
+static int cons_vote_view(const pba_cons *c, ConsDev *dev, int *beg, int *pre, int *post);
+
+// Edit scripts of a batch (vote == nullptr: ops / ops_off / nedit receive them) or their votes (vote != nullptr: the
+// paths go straight into its boxes, gated by overlap_min; ops / ops_off / nedit unused).
+static int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
+                       int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
+                       int32_t *nedit, const pba_cons *vote, int overlap_min) {
+    if (!ctx || !A || !B || (!pairs && n) || (!out && n) || (!vote && ((!ops_off && n) || (!nedit && n)))) return PBA_E_INVALID;
     if (n == 0) return PBA_OK;
     if (n > 0x7FFFFFFFull) PBA_FAIL(PBA_E_INVALID, "too many pairs in one batch");
     if (A->non_acgt || B->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "a sequence set holds bytes outside ACGT: use pba_align_text_trace");
@@ -1210,7 +1246,7 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
         if (!pair_ok(A, p.a_seq, p.a_pos, p.a_len, p.flags & PBA_A_BACKWARD) ||
             !pair_ok(B, p.b_seq, p.b_pos, p.b_len, p.flags & PBA_B_BACKWARD))
             PBA_FAIL(PBA_E_INVALID, "pair outside its sequence (or longer than the engine limit)");
-        if (ops_off[q + 1] < ops_off[q] || ops_off[q + 1] - ops_off[q] < (uint64_t)p.a_len + p.b_len)
+        if (!vote && (ops_off[q + 1] < ops_off[q] || ops_off[q + 1] - ops_off[q] < (uint64_t)p.a_len + p.b_len))
             PBA_FAIL(PBA_E_INVALID, "ops_off must leave a_len + b_len slots per pair");
         if (R > 0.0 && R < 1.0) mdmax = std::max(mdmax, max_dst_of(p.a_len, p.b_len, R));
         ops_max = std::max(ops_max, (uint64_t)p.a_len + p.b_len);
@@ -1218,15 +1254,23 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
     Plan pl;
     int st = make_plan(ctx, R, maxn, maxm, kernel, mdmax, &pl);
     if (st != PBA_OK) return st;
-    const uint64_t ops_total = ops_off[n] - ops_off[0];
+    ConsDev vdev = {nullptr, nullptr, nullptr, nullptr};
+    int vbeg = 0, vpre = 0, vpost = 0;
+    if (vote) {
+        if (pl.nb1 == 0) PBA_FAIL(PBA_E_TOOLONG, "votes from the walk need the bit-vector kernel (band too wide)");
+        st = cons_vote_view(vote, &vdev, &vbeg, &vpre, &vpost);
+        if (st != PBA_OK) return st;
+        ops_max = 0;                                             // no goal-first temporary
+    }
+    const uint64_t ops_total = vote ? 0 : ops_off[n] - ops_off[0];
     DevBuf d_pairs, d_out, d_par, d_poff, d_ops, d_ooff, d_ne;
     HIPCHK(hipMalloc(&d_pairs.p, sizeof(pba_pair) * n));
     HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result) * n));
     HIPCHK(hipMalloc(&d_ops.p, ops_total + 16));
     HIPCHK(hipMalloc(&d_ooff.p, sizeof(uint64_t) * (n + 1)));
     HIPCHK(hipMalloc(&d_ne.p, sizeof(int32_t) * n));
-    std::vector<uint64_t> rel(n + 1);
-    for (size_t q = 0; q <= n; ++q) rel[q] = ops_off[q] - ops_off[0];
+    std::vector<uint64_t> rel(n + 1, 0);
+    if (!vote) for (size_t q = 0; q <= n; ++q) rel[q] = ops_off[q] - ops_off[0];
     HIPCHK(hipMemcpyAsync(d_pairs.p, pairs, sizeof(pba_pair) * n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_ooff.p, rel.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
     size_t free_b = 0, total_b = 0;
@@ -1285,10 +1329,15 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
             HIPCHK(hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
             (void)hipEventRecord(ctx->ev[pass ? 4 : 2], ctx->stream);
 #define K_TRACE(NBV)                                                                                                  \
-    hipLaunchKernelGGL(k_trace_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(),  \
-                       d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), d_scr.as<uint32_t>(),         \
-                       wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(), d_ne.as<int32_t>(),          \
-                       ctx->d_queue)
+    if (vote)                                                                                                         \
+        hipLaunchKernelGGL(k_vote_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
+                           d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, overlap_min, d_out.as<pba_result>(),              \
+                           d_scr.as<uint32_t>(), wave_words, cap_words, vdev, vbeg, vpre, vpost, ctx->d_queue);        \
+    else                                                                                                              \
+        hipLaunchKernelGGL(k_trace_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
+                           d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), d_scr.as<uint32_t>(),     \
+                           wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(), d_ne.as<int32_t>(),      \
+                           ctx->d_queue)
             switch (nb) {
                 case 1: K_TRACE(1); break;
                 case 2: K_TRACE(2); break;
@@ -1310,11 +1359,19 @@ int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, co
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(nedit, d_ne.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
-    if (ops_total) HIPCHK(hipMemcpyAsync(ops + ops_off[0], d_ops.p, ops_total, hipMemcpyDeviceToHost, ctx->stream));
+    if (!vote) {
+        HIPCHK(hipMemcpyAsync(nedit, d_ne.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+        if (ops_total) HIPCHK(hipMemcpyAsync(ops + ops_off[0], d_ops.p, ops_total, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     prof_finish(ctx);
     return PBA_OK;
+}
+
+int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
+                          int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
+                          int32_t *nedit) {
+    return trace_batch(ctx, A, B, pairs, n, R, maxn, maxm, kernel, out, ops, ops_off, nedit, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1844,6 +1901,27 @@ int pba_cons_elect(pba_ctx *ctx, pba_cons *c, uint32_t n, const int32_t *pos, co
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PBA_OK;
+}
+
+static int cons_vote_view(const pba_cons *c, ConsDev *dev, int *beg, int *pre, int *post) {
+    if (!c) return PBA_E_INVALID;
+    *dev = c->set[c->cur]; *beg = c->beg; *pre = c->pre; *post = c->post;
+    return PBA_OK;
+}
+
+// ref_seq::try_align's align + gate + elect (ref_seq.h:264-267) for a batch of pairs whose `a` is the reference:
+// sweep, walk and vote on the device, no script in memory.  No growth (append / prepend are the caller's, after the
+// batch): the batch form of a round of interior reads.
+int pba_cons_vote_pairs(pba_ctx *ctx, pba_cons *c, const pba_seqs *A, uint32_t ref_seq, const pba_seqs *B,
+                        const pba_pair *pairs, size_t n, double R, int maxn, int maxm, int overlap_min, pba_result *out) {
+    if (!ctx || !c || !A || !B || (!pairs && n) || (!out && n) || ref_seq >= A->n) return PBA_E_INVALID;
+    if ((int)A->h_len[ref_seq] != c->end - c->beg) PBA_FAIL(PBA_E_INVALID, "pba_cons_vote_pairs: A[ref_seq] is not the reference of these boxes");
+    for (size_t q = 0; q < n; ++q) {
+        const bool ab = (pairs[q].flags & PBA_A_BACKWARD) != 0, bb = (pairs[q].flags & PBA_B_BACKWARD) != 0;
+        if (pairs[q].a_seq != ref_seq || ab != bb)               // try_align walks both accessors the same way (ref_seq.h:260-261)
+            PBA_FAIL(PBA_E_INVALID, "pba_cons_vote_pairs: a must be the reference, both accessors in one direction");
+    }
+    return trace_batch(ctx, A, B, pairs, n, R, maxn, maxm, PBA_KERNEL_BITVEC, out, nullptr, nullptr, nullptr, c, overlap_min);
 }
 
 int pba_cons_evolve(pba_ctx *ctx, pba_cons *c, char *text_out, int cap, int32_t *new_len) {   // ref_seq.h:317-349

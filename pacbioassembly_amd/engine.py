@@ -401,6 +401,15 @@ class Consensus:
         self.ctx.check(self.ctx.lib.pba_cons_elect(self.ctx.h, self.h, n, _ptr(pos), _ptr(fw), _ptr(ops), _ptr(vb), _ptr(off),
                                                    _ptr(ne)), "cons_elect")
 
+    def vote_pairs(self, A: "SeqSet", ref_seq: int, B: "SeqSet", pairs: np.ndarray, R: float, overlap_min: int = 64,
+                   maxn: int = 0, maxm: int = 0) -> np.ndarray:
+        """align + gate + elect for a batch, on the device (pba_cons_vote_pairs); returns the alignment results."""
+        pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+        out = np.zeros(max(pairs.size, 1), RESULT_DTYPE)
+        self.ctx.check(self.ctx.lib.pba_cons_vote_pairs(self.ctx.h, self.h, A.h, ref_seq, B.h, _ptr(pairs), pairs.size, R, maxn, maxm,
+                                                        overlap_min, _ptr(out)), "cons_vote_pairs")
+        return out[:pairs.size]
+
     def evolve(self) -> bytes:
         cap = 3 * self.max_len
         buf = C.create_string_buffer(cap)

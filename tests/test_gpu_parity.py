@@ -789,3 +789,44 @@ def test_edge_cases_of_the_widened_entry_points(ctx, oracle):
     one = ctx.seqs_from_list([b"ACGT" * 300])
     ov, st = ctx.overlap_all(one, 0xFFCCF3FC, 0.3, 8, 64)
     assert ov.size == 0 and st["n_overlaps"] == 0
+
+
+def test_cons_vote_pairs_equals_scripts_then_elect(ctx):
+    """pba_cons_vote_pairs (sweep, walk and vote on the device, no script in memory) == edit scripts from
+    pba_align_batch_trace applied with pba_cons_elect behind the OVERLAP_MIN gate: same boxes, same evolved text; forward
+    and backward tries, reads running off both ends of the reference (their votes past it are dropped alike)."""
+    from cons_scenarios import round_tries, scenario_inputs
+    sc = ("vote", 151, 152, 8000, 2000, 3500, 120, 1300, 2, (0.05, 0.05, 0.05), True)
+    text, weight, reads = scenario_inputs(sc)
+    A = ctx.seqs_from_list([b"ACGT" * 10, text], strict_acgt=True)       # the reference is sequence 1 of its set
+    B = ctx.seqs_from_list(reads, strict_acgt=True)
+    pairs = []
+    for rnd in (0, 1):
+        for hit, r, seg, fwd in round_tries(text, reads, rnd):
+            if fwd:
+                pairs.append((1, hit, len(text) - hit, r, len(reads[r]) - len(seg), len(seg), 0))
+            else:
+                pairs.append((1, hit, hit + 1, r, len(seg) - 1, len(seg), 3))
+    pairs = np.array(pairs, PAIR_DTYPE)
+    assert pairs.size >= 30 and (pairs["flags"] == 3).sum() >= 8
+    one, many = eng.Consensus(ctx, text, weight), eng.Consensus(ctx, text, weight)
+    out, scripts = ctx.align_batch_trace(A, B, pairs, 0.3)
+    n_voted = 0
+    for pr, res, ops in zip(pairs, out, scripts):
+        if int(res["rc"]) < 0 or int(res["matlen_a"]) < 64:
+            continue
+        fwd = int(pr["flags"]) == 0
+        rd = reads[int(pr["b_seq"])]
+        seg = rd[int(pr["b_pos"]):] if fwd else rd[:int(pr["b_pos"]) + 1]
+        one.elect([int(pr["a_pos"])], [fwd], [ops], [eng.script_vals(ops, seg, fwd)])
+        n_voted += 1
+    out2 = many.vote_pairs(A, 1, B, pairs, 0.3, 64)
+    assert n_voted >= 20
+    for c in ("rc", "cost", "matlen_a", "matlen_b"):
+        assert (out[c] == out2[c]).all(), c
+    for x, y in zip(one.dump()[:3], many.dump()[:3]):
+        assert (x == y).all()
+    assert one.evolve() == many.evolve()
+    with pytest.raises(PbaError) as e:                               # a must be the reference of these boxes
+        many.vote_pairs(A, 0, B, pairs[:1], 0.3, 64)
+    assert e.value.status == -1
