@@ -243,6 +243,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         t_next = min(min(t_evt, t_seg + 1), min(t_dstart, t <= t_hin_end ? t_hin_end + 1 : INT_MAX)); \
       }                                                                               \
       valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);   /* changes only at events: kept as a scalar mask */ \
+      if constexpr (TRACE) st_on = ((__builtin_amdgcn_ballot_w64(opened != 0) >> (lane & 48)) & 0xFFFFull) != 0; \
       ON_EVENT;                                                                       \
     }
 
@@ -278,6 +279,8 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     // the loop loses its increment on the text-refill path of the step loop (ROCm 7.2 clang, seen in the ISA)
     uint2 *const tr_lane = (uint2 *)tr + lane;
     (void)tr_lane;
+    bool st_on = false;          // TRACE: some lane of this lane's 16-lane group is inside its window (updated at events)
+    (void)st_on;
 #define PBA_BV_TRP() (tr_lane + (size_t)(t - 1) * (NB * 64))
     // ------------------------------------------------------------------ phase 1: down to cell (m,m)
     // The step loop is cut into chunks of 32 steps (one pair of text planes): the scalar unit is shared by the CU's
@@ -301,8 +304,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             uint32_t d0, php, mhp, eq;
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
             (void)php; (void)mhp; (void)eq;
-            if constexpr (TRACE)             // all 64 lanes store (512 contiguous bytes per instruction): masking the lanes
-                PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);   // outside their window was measured 1.5x SLOWER
+            if constexpr (TRACE) {           // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
+                if (st_on)                   // inside its window (masking lane by lane was measured 1.5x SLOWER: partial lines)
+                    PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);
+            }
             // keep the diagonal cell's D0 bit (garbage while the diagonal is in another block: the word is
             // cleared when the diagonal enters)
             acc[nb] = or_of_and(acc[nb], d0, dmw);
@@ -344,8 +349,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
             (void)d0; (void)eq;
             if (nb == nb_m) { ph_m = php; mh_m = mhp; }
-            if constexpr (TRACE)             // all 64 lanes store (512 contiguous bytes per instruction): masking the lanes
-                PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);   // outside their window was measured 1.5x SLOWER
+            if constexpr (TRACE) {           // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
+                if (st_on)                   // inside its window (masking lane by lane was measured 1.5x SLOWER: partial lines)
+                    PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);
+            }
         }
         hp_last = hp; hn_last = hn;
         if (owner) {                             // D(m,j) = D(m,j-1) + horizontal delta at row m (seq_aligner.h:202-211)

@@ -32,6 +32,8 @@ struct pba_ctx {
     hipDeviceProp_t prop;
     hipEvent_t ev[6];        // index begin/end, align begin/end, redo begin/end
     uint32_t *d_queue;       // work-queue counters of the persistent aligning kernels (one per launch in flight)
+    void *d_scratch;         // parent-bit scratch of the trace / vote kernels, kept between calls (tens of GB: mapping
+    size_t scratch_bytes;    // it anew on every call cost seconds); grown on demand, freed with the ctx
     pba_profile prof;
     char err[512];
 };
@@ -542,6 +544,7 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PBA_E_HIP; }
     memset(&ctx->prof, 0, sizeof ctx->prof);
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
+    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
     // kernels that take more than the default 64 KB of dynamic LDS
     const int big = 160 * 1024;
     (void)hipFuncSetAttribute((const void *)k_part_sort, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -562,6 +565,7 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     (void)hipStreamDestroy(ctx->own_stream);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ctx->ev[i]);
     (void)hipFree(ctx->d_queue);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     delete ctx;
 }
 
@@ -1275,6 +1279,7 @@ static int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const
     HIPCHK(hipMemcpyAsync(d_ooff.p, rel.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    free_b += ctx->scratch_bytes;                            // the scratch kept from earlier calls is ours to reuse
     uint64_t budget = std::min<uint64_t>(kTraceBudget, (uint64_t)(free_b / 10) * 8);
     if (const char *e = getenv("PBA_TRACE_BUDGET_GB"))       // tuning aid: HBM the parent bits / codes of one call may take
         budget = std::min<uint64_t>((uint64_t)atoll(e) << 30, (uint64_t)(free_b / 10) * 9);
@@ -1317,8 +1322,15 @@ static int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const
             uint32_t grid = persistent_grid(ctx, cnt, 4, pl.lds);
             grid = (uint32_t)std::min<uint64_t>(grid, budget / (wave_words * 4 * 4));
             if (grid == 0) PBA_FAIL(PBA_E_NOMEM, "one wavefront's parent bits exceed the traceback budget");
-            DevBuf d_scr, d_ids;
-            HIPCHK(hipMalloc(&d_scr.p, (size_t)grid * 4 * wave_words * 4));
+            DevBuf d_ids;
+            const size_t need = (size_t)grid * 4 * wave_words * 4;
+            if (need > ctx->scratch_bytes) {
+                if (ctx->d_scratch) { HIPCHK(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_scratch); }
+                ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+                HIPCHK(hipMalloc(&ctx->d_scratch, need));
+                ctx->scratch_bytes = need;
+            }
+            uint32_t *const d_scr = (uint32_t *)ctx->d_scratch;
             const uint32_t *ids = nullptr;
             if (pass) {
                 HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * cnt));
@@ -1332,10 +1344,10 @@ static int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const
     if (vote)                                                                                                         \
         hipLaunchKernelGGL(k_vote_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
                            d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, overlap_min, d_out.as<pba_result>(),              \
-                           d_scr.as<uint32_t>(), wave_words, cap_words, vdev, vbeg, vpre, vpost, ctx->d_queue);        \
+                           d_scr, wave_words, cap_words, vdev, vbeg, vpre, vpost, ctx->d_queue);        \
     else                                                                                                              \
         hipLaunchKernelGGL(k_trace_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
-                           d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), d_scr.as<uint32_t>(),     \
+                           d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), d_scr,     \
                            wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(), d_ne.as<int32_t>(),      \
                            ctx->d_queue)
             switch (nb) {

@@ -40,17 +40,23 @@ for rep in range(a.reps + 1):                       # first pass = warm-up
 assert (out["rc"] > 0).all() and (out["cost"] == hit["cost"]).all()
 nedit = np.array([s.size for s in scripts])
 ms = best[0]
-# bytes the forward pass streams: steps * NB * 2 words * 64 lanes * 4 B (align_bvtrace.h), NB and the band from the profile
+# parent bits of the cells the sweep processes: 2 words per (column of a superblock's window, block): the algorithmic
+# figure; what is actually stored (whole 128-byte lines of the 16-lane groups with an open window) is the PMC's WRITE_SIZE
 nb = int(prof["nb_first"])
-m = int(np.median(pairs["a_len"])); w = max(md // 2, md * 9 // 16) + 1
-S = -(-m // (32 * nb)) if nb else 0
-steps = min(m + md, (S - 1) * 32 * nb + 32 * nb + w) + S - 1 if nb else 0
-stream = steps * nb * 512 if nb else (m + 1) * (2 * md + 1)
+m = int(np.median(pairs["a_len"])); w = max(md // 2, md * 9 // 16) + 1; wl = w // 2 + 1
+n_cols = min(int(np.median(pairs["b_len"])), m + md)
+if nb:
+    rb = 32 * nb
+    S = -(-m // rb)
+    cols = sum(min(n_cols, s * rb + rb + w) - max(1, s * rb + 1 - wl) + 1 for s in range(S))
+    stream = cols * nb * 8
+else:
+    stream = (m + 1) * (2 * md + 1)
 cells_ref = float(np.mean((pairs["a_len"].astype(np.float64) + 1) * (2 * md + 1)))
 print(json.dumps({"workload": f"traceback of {hit.size} true {a.read_len}-base pairs @15% (R={a.R}), kernel={'auto' if not a.kernel else a.kernel}",
                   "pairs": int(hit.size), "kernel_ms": round(ms, 2), "wall_s_with_d2h": round(best[1], 3),
                   "scripts_per_s": round(hit.size / (ms / 1e3), 1), "mean_nedit": float(nedit.mean()), "nb": nb,
-                  "parent_bytes_streamed_per_pair": int(stream), "hbm_write_GBps": round(hit.size * stream / (ms / 1e3) / 1e9, 1),
+                  "parent_bits_bytes_per_pair": int(stream), "hbm_write_GBps": round(hit.size * stream / (ms / 1e3) / 1e9, 1),
                   "frac_of_8TBps": round(hit.size * stream / (ms / 1e3) / 8e12, 4),
                   "survey_fig_bytes_per_pair(cells/4)": int(cells_ref / 4),
                   "survey_fig_GBps": round(hit.size * cells_ref / 4 / (ms / 1e3) / 1e9, 1)}))

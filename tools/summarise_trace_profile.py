@@ -18,12 +18,13 @@ for sub in ("pmc_fetch", "pmc_write"):
 st = [r for r in csv.DictReader(open(f"profiles/{rp}_trace_kernel_stats.csv")) if "k_trace_pairs" in r["Name"]][0]
 avg_ms = float(st["AverageNs"]) / 1e6
 wb = out["pmc"]["WRITE_SIZE_KB_per_launch"] * 1024; fb = out["pmc"]["FETCH_SIZE_KB_per_launch"] * 1024
-alg = plain["pairs"] * plain["parent_bytes_streamed_per_pair"]
+alg = plain["pairs"] * plain["parent_bits_bytes_per_pair"]
 out["roofline"] = {"bound": "hbm", "kernel": st["Name"].split("(")[0].replace("void ", ""), "launch_ms_rocprof": round(avg_ms, 3),
                    "algorithmic_bytes_per_launch": alg, "achieved": round(alg / avg_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                    "frac": round(alg / avg_ms / 1e6 / 8000, 4), "traffic": int(wb + 2 * fb), "pmc_write_bytes": int(wb),
                    "pmc_fetch_bytes_raw": int(fb),
-                   "note": "algorithmic = parent bits streamed by the forward pass (steps x NB x 2 words x 64 lanes x 4 B per pair); "
-                           "reads are the walk's 64-step tiles (raw FETCH_SIZE, x2 in traffic per the gfx950 correction)"}
+                   "note": "algorithmic = 2 parent bits per cell the sweep processes (window columns x NB x 8 B per pair); the kernel stores whole "
+                           "128-byte lines of the 16-lane groups with an open window (pmc_write_bytes); reads are the walk's 64-step "
+                           "tiles (raw FETCH_SIZE, x2 in traffic per the gfx950 correction)"}
 json.dump(out, open(f"profiles/{rp}_trace_bench.json", "w"), indent=1)
 print(json.dumps(out["roofline"]))
