@@ -219,7 +219,7 @@ int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int a_len, cons
 /* Batch form on packed sets: pair q's script goes to ops[ops_off[q] .. ops_off[q+1]) (needs a_len + b_len
  * slots), its length to nedit[q] (0 when rc < 0).  kernel: PBA_KERNEL_AUTO / _BITVEC run the bit-vector array
  * and stream 2 parent bits per processed cell into a per-wavefront scratch area that the same wavefront walks
- * back (HBM-bound: ~18 MB written per 15 kb pair, any batch size); PBA_KERNEL_ROWSWEEP keeps one parent byte
+ * back (HBM-bound: ~16 MB written per 15 kb pair, any batch size); PBA_KERNEL_ROWSWEEP keeps one parent byte
  * per band cell for every pair of the batch at once (135 MB per 15 kb pair; the cross-check). */
 int pba_align_batch_trace(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n,
                           double R, int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops,
