@@ -830,3 +830,34 @@ def test_cons_vote_pairs_equals_scripts_then_elect(ctx):
     with pytest.raises(PbaError) as e:                               # a must be the reference of these boxes
         many.vote_pairs(A, 0, B, pairs[:1], 0.3, 64)
     assert e.value.status == -1
+
+
+def test_overlap_all_with_tandem_repeats(ctx, oracle):
+    """Reads that share a tandem repeat: one probe hits hundreds of positions of every other read, so a (target, query)
+    run is thousands of candidates long -- it spans many 64-candidate work items (the owner rule), a target's list
+    outgrows the LDS sort, and the first success sits deep inside a run.  Same answer as the oracle's composition."""
+    rng = np.random.RandomState(5)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    unit = alpha[rng.randint(0, 4, 23)].tobytes()
+    g = eng.synth_genome(91, 6000).tobytes()
+    genome = g[:2000] + unit * 70 + g[2000:]                      # 1 610 bases of period 23 inside a 7.6 kb genome
+    garr = np.frombuffer(genome.encode() if isinstance(genome, str) else genome, np.uint8)
+    reads, offs, _ = eng.synth_reads(92, garr, 24, 2600, 0.02, 0.02, 0.02)
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(24)]
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    want, pairs = [], 0
+    for t in range(24):
+        rows = oracle.spaced_round(texts[t], mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=8)
+        pairs += int(rows["n_pairs"].sum()) - int(rows["n_pairs"][t])
+        for q in range(24):
+            if q != t and rows["found"][q]:
+                want.append((t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]),
+                             int(rows["matlen_a"][q]), int(rows["matlen_b"][q])))
+    S = ctx.seqs_from_list(texts, strict_acgt=True)
+    for kernel in KERNELS:
+        got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=kernel)
+        assert [tuple(int(x) for x in r) for r in got] == want, kernel
+        assert st["n_pairs"] == pairs and st["n_candidates"] > 20 * st["n_pairs"] / 10
+    assert len(want) > 100 and pairs > 3000
