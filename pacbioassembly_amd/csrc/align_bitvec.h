@@ -77,17 +77,23 @@ __device__ __forceinline__ uint32_t compress_even64(uint64_t x) {
 }
 
 // bit planes of 32 consecutive accessor elements starting at element e: bit r of plo/phi = low/high bit of
-// element e+r
+// element e+r.  From the set's precomputed planes: two dword loads and one funnel shift per plane (the index may run
+// a few hundred bases before / past the sequence: neighbours or zero slack, never used).
 __device__ __forceinline__ void load_planes32(const PackedFetch &f, int e, uint32_t &plo, uint32_t &phi) {
-    if (f.dir > 0) {
-        const uint64_t x = load_bases32(f.seq, f.org + e);            // element r at bits 63-2r : 62-2r
-        plo = __builtin_bitreverse32(compress_even64(x));
-        phi = __builtin_bitreverse32(compress_even64(x >> 1));
-    } else {
-        const uint64_t x = load_bases32(f.seq, f.org - e - 31);       // element r (base org-e-r) at bits 2r+1 : 2r
-        plo = compress_even64(x);
-        phi = compress_even64(x >> 1);
-    }
+    const int idx = f.dir > 0 ? f.org + e : f.org - e - 31;          // lowest base index of the 32, in memory order
+    const uint32_t *p = f.pl + (idx >> 5);                            // (arithmetic shift: negative indices reach the slack)
+    const uint32_t sh = (uint32_t)idx & 31u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(p[1], p[0], sh);    // ({p[1], p[0]} >> sh)[31:0]
+    const uint32_t hi = __builtin_amdgcn_alignbit(p[f.hi + 1], p[f.hi], sh);
+    plo = f.dir > 0 ? lo : __builtin_bitreverse32(lo);                // backward: element r is base idx + 31 - r
+    phi = f.dir > 0 ? hi : __builtin_bitreverse32(hi);
+}
+
+// the planes of 32 bases from the packed bytes (k_make_planes builds a set's planes with this, once)
+__device__ __forceinline__ void planes_from_packed(const uint8_t *seq, int idx, uint32_t &plo, uint32_t &phi) {
+    const uint64_t x = load_bases32(seq, idx);                        // base idx + r at bits 63-2r : 62-2r
+    plo = __builtin_bitreverse32(compress_even64(x));
+    phi = __builtin_bitreverse32(compress_even64(x >> 1));
 }
 
 // d = a + b + carry-in, carry-out to a lane mask: v_addc_co_u32 with SGPR-pair carries.  One instruction does

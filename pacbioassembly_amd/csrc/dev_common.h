@@ -14,6 +14,12 @@ struct SeqSetDev {
     const uint8_t *packed;   // all sequences; >= 64 readable bytes after the last one
     const uint64_t *off;     // byte offset of sequence i's first packed byte
     const uint32_t *len;     // length in bases
+    // The same bases as two bit planes (bit p of sequence i's stream = low / high bit of its base p, LSB first, every
+    // sequence starting on a word): what the bit-vector kernels consume.  Built once per set (k_make_planes) so that
+    // 32 bases of either plane are two dword loads and a funnel shift instead of a 60-instruction bit de-interleave.
+    const uint32_t *plane;   // low plane; >= 32 zero words before the first and after the last sequence
+    const uint64_t *poff;    // word offset of sequence i in a plane
+    uint64_t hi_words;       // words from the low plane to the high plane
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
@@ -43,11 +49,21 @@ struct PackedFetch {
     const uint8_t *seq;   // first packed byte of the sequence
     int org;              // accessor origin (base index)
     int dir;              // +1 forward, -1 backward
+    const uint32_t *pl;   // the sequence's first word in the low bit plane
+    uint64_t hi;          // words from the low plane to the high plane
     __device__ __forceinline__ int operator()(int k) const {
         const int idx = org + dir * k;
         return (seq[idx >> 2] >> (6 - 2 * (idx & 3))) & 3;
     }
+    // the same sequence from another origin / in another direction
+    __device__ __forceinline__ PackedFetch at(int origin, int direction) const {
+        return PackedFetch{seq, origin, direction, pl, hi};
+    }
 };
+// accessor on sequence `id` of a set (dna_seq.h:191: origin + direction)
+__device__ __forceinline__ PackedFetch fetch_of(const SeqSetDev &S, uint32_t id, int org, int dir) {
+    return PackedFetch{S.packed + S.off[id], org, dir, S.plane + S.poff[id], S.hi_words};
+}
 struct ByteFetch {
     const uint8_t *org;   // accessor origin (pointer to element 0)
     int dir;

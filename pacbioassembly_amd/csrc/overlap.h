@@ -195,7 +195,7 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             if (c_begin > cand_off[tl]) skip_q = (uint32_t)(cand[c_begin - 1] >> PBA_OVL_Q_SHIFT);   // a run begun in the previous group
         }
         const uint32_t t = t_lo + tl;
-        const uint8_t *ref = Rd.packed + Rd.off[t];
+        const PackedFetch ref = fetch_of(Rd, t, 0, 1);
         const int ref_len = (int)Rd.len[t];
         const HeadTail ht(ref_len);
         uint32_t done_q = NONE, last_q = NONE;
@@ -215,9 +215,8 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             if constexpr (NB != 0) {
                 const OvlCand m = ovl_decode(Rd, ref_len, ht, mycd, cfg);
                 AlnOut po;
-                myfr = prefilter32(act && m.ok, PackedFetch{ref, m.r_off, m.fwd ? 1 : -1}, m.r_len,
-                                   PackedFetch{Rd.packed + Rd.off[act ? m.q : 0], m.s_off, m.fwd ? 1 : -1}, m.s_len, cfg.R, 0, 0,
-                                   pre_t, po);
+                myfr = prefilter32(act && m.ok, ref.at(m.r_off, m.fwd ? 1 : -1), m.r_len,
+                                   fetch_of(Rd, act ? m.q : 0, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R, 0, 0, pre_t, po);
             }
             for (uint32_t k = 0; k < ng; ++k) {
                 const uint32_t c = c0 + k;
@@ -232,8 +231,8 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
                 if (__builtin_amdgcn_readlane(myfr, (int)k)) { ++pairs; continue; }   // failed within its first 32 rows
                 const OvlCand m = ovl_decode(Rd, ref_len, ht, cd, cfg);
                 if (!m.ok) continue;
-                PackedFetch fa{ref, m.r_off, m.fwd ? 1 : -1};               // a = the target in the reference role (ref_seq.h:264)
-                PackedFetch fb{Rd.packed + Rd.off[q], m.s_off, m.fwd ? 1 : -1};
+                const PackedFetch fa = ref.at(m.r_off, m.fwd ? 1 : -1);      // a = the target in the reference role (ref_seq.h:264)
+                const PackedFetch fb = fetch_of(Rd, q, m.s_off, m.fwd ? 1 : -1);
                 AlnOut o;
                 if constexpr (NB == 0) align_rowsweep(fa, m.r_len, fb, m.s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
                 else align_bitvec<NB>(fa, m.r_len, fb, m.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);

@@ -38,6 +38,7 @@ struct pba_ctx {
     char err[512];
 };
 
+static const size_t kPlaneSlack = 64;           // zero words before the first and after the last sequence of a bit plane
 struct pba_seqs {
     pba_ctx *ctx;
     uint32_t n, max_len;
@@ -47,9 +48,12 @@ struct pba_seqs {
     uint8_t *d_packed;
     uint64_t *d_off;
     uint32_t *d_len;
+    uint32_t *d_planes;      // allocation of the two bit planes (low, then high), kPlaneSlack zero words around each
+    uint64_t *d_poff;        // word offset of every sequence inside a plane
+    uint64_t plane_words;    // words of one plane incl. its slack
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
-    SeqSetDev dev() const { return SeqSetDev{d_packed, d_off, d_len}; }
+    SeqSetDev dev() const { return SeqSetDev{d_packed, d_off, d_len, d_planes + kPlaneSlack, d_poff, plane_words}; }
 };
 
 struct pba_index {
@@ -121,6 +125,30 @@ k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_of
     if (notacgt) atomicOr(bad, 1u);
 }
 
+// Bit planes of a packed set (dev_common.h: SeqSetDev::plane): thread w owns plane word w of the whole set.
+__global__ void __launch_bounds__(256)
+k_make_planes(const uint8_t *packed, const uint64_t *off, const uint32_t *len, const uint64_t *poff, uint32_t n,
+              uint64_t total_words, uint32_t *plane_lo, uint64_t hi_words) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= total_words) return;
+    uint32_t lo = 0, hi = n;            // last s with poff[s] <= w
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (poff[mid] <= w) lo = mid; else hi = mid;
+    }
+    const uint32_t s = lo;
+    const uint64_t k = w - poff[s];     // word index inside the sequence
+    const uint32_t L = len[s];
+    uint32_t plo = 0, phi = 0;
+    if (k * 32 < L) {
+        planes_from_packed(packed + off[s], (int)(k * 32), plo, phi);
+        const uint32_t valid = L - (uint32_t)(k * 32);
+        if (valid < 32) { plo &= (1u << valid) - 1u; phi &= (1u << valid) - 1u; }   // nothing of the neighbour's bytes
+    }
+    plane_lo[w] = plo;
+    plane_lo[w + hi_words] = phi;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernels: alignment of explicit pairs
 // ---------------------------------------------------------------------------------------------
@@ -190,8 +218,8 @@ k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *i
         if (slot >= n) break;
         const uint32_t q = ids ? ids[slot] : slot;
         const pba_pair pr = pairs[q];
-        PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
-        PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+        const PackedFetch fa = fetch_of(A, pr.a_seq, pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1);
+        const PackedFetch fb = fetch_of(B, pr.b_seq, pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1);
         AlnOut o;
         align_dispatch<NB>(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
         store_result(out + q, o);
@@ -216,8 +244,8 @@ k_align_pairs_trace(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n,
     const uint32_t q = blockIdx.x;
     if (q >= n) return;
     const pba_pair pr = pairs[q];
-    PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
-    PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+    const PackedFetch fa = fetch_of(A, pr.a_seq, pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1);
+    const PackedFetch fb = fetch_of(B, pr.b_seq, pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1);
     AlnOut o;
     align_rowsweep(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o, par + par_off[q]);
     store_result(out + q, o);
@@ -250,8 +278,8 @@ k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *i
         if (slot >= n) break;
         const uint32_t q = ids ? ids[slot] : slot;
         const pba_pair pr = pairs[q];
-        PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1};
-        PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+        const PackedFetch fa = fetch_of(A, pr.a_seq, pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1);
+        const PackedFetch fb = fetch_of(B, pr.b_seq, pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1);
         AlnOut o;
         int ne = 0;
         const uint64_t o0 = ops_off[q], o1 = ops_off[q + 1];
@@ -282,8 +310,8 @@ k_vote_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *id
         const uint32_t q = ids ? ids[slot] : slot;
         const pba_pair pr = pairs[q];
         const bool fwd = !(pr.flags & PBA_A_BACKWARD);
-        PackedFetch fa{A.packed + A.off[pr.a_seq], pr.a_pos, fwd ? 1 : -1};
-        PackedFetch fb{B.packed + B.off[pr.b_seq], pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1};
+        const PackedFetch fa = fetch_of(A, pr.a_seq, pr.a_pos, fwd ? 1 : -1);
+        const PackedFetch fb = fetch_of(B, pr.b_seq, pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1);
         AlnOut o;
         VoteSink sink{C, beg + pr.a_pos, pre, post, fwd, fb, 0, 0, 0, 0u};
         if (align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
@@ -352,8 +380,8 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
     int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0, redo = 0;
     long long ncell = 0;
     if (len >= min_len) {                                                   // locator.cpp:72
-        const uint8_t *rseq = Rd.packed + Rd.off[r];
-        const uint8_t *tsq = T.packed + T.off[tseq];
+        const PackedFetch rbase = fetch_of(Rd, r, 0, 1), tbase = fetch_of(T, tseq, 0, 1);
+        const uint8_t *rseq = rbase.seq;
         const int clen = (int)T.len[tseq];
         for (int j = 0; j < trials && j < len && !found && !redo; ++j) {    // locator.cpp:74
             const uint32_t key = window_key(rseq, (uint32_t)j, (uint32_t)len) & ix.mask;   // locator.cpp:75
@@ -372,7 +400,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
                 long long mycells = 0;
                 if constexpr (NB != 0) {
                     AlnOut po;
-                    myfr = prefilter32(act, PackedFetch{rseq, j, 1}, len - j, PackedFetch{tsq, mypos, 1}, clen - mypos, cfg.R,
+                    myfr = prefilter32(act, rbase.at(j, 1), len - j, tbase.at(mypos, 1), clen - mypos, cfg.R,
                                        cfg.maxn, cfg.maxm, pre_t, po);
                     mycells = myfr ? band_cells(po.len_b, po.max_dst, myfr) : 0;
                 }
@@ -385,8 +413,8 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
                         continue;
                     }
                     const int pos = __builtin_amdgcn_readlane(mypos, (int)hh);
-                    PackedFetch fa{rseq, j, 1};                             // a = read from j   (locator.cpp:78)
-                    PackedFetch fb{tsq, pos, 1};                            // b = contig from pos (locator.cpp:80)
+                    const PackedFetch fa = rbase.at(j, 1);                  // a = read from j   (locator.cpp:78)
+                    const PackedFetch fb = tbase.at(pos, 1);                // b = contig from pos (locator.cpp:80)
                     AlnOut o;
                     align_dispatch<NB>(fa, len - j, fb, clen - pos, cfg, lds, o);
                     if (o.rc == PBA_RC_UNCERTIFIED) { redo = 1; break; }
@@ -420,9 +448,10 @@ struct SsState {
 };
 
 template <int NB>
-__device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, int ref_len, const uint8_t *rseq,
+__device__ __forceinline__ bool ss_try(const IndexDev &ix, const PackedFetch &refb, int ref_len, const PackedFetch &readb,
                                        int slen, int pos, int dir, int overlap_min, int buggy, const AlignCfg &cfg,
                                        const PreThresholds &pre_t, void *lds, SsState &st) {
+    const uint8_t *rseq = readb.seq;
     if (pos < 0 || pos + 16 > slen) return false;   // the reference only keeps reads > 500 bases
     const uint32_t key = seed_at_dev(rseq, pos, (uint32_t)slen, buggy) & ix.mask;   // spaced_seed.cpp:265
     if (key == 0) return false;
@@ -442,16 +471,16 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const uint8_t *ref, i
         if constexpr (NB != 0) {
             const int r_off = fwd ? myhit : myhit + 15;
             AlnOut po;
-            myfr = prefilter32(act, PackedFetch{ref, r_off, fwd ? 1 : -1}, fwd ? ref_len - r_off : r_off + 1,
-                               PackedFetch{rseq, s_off, fwd ? 1 : -1}, s_len, cfg.R, cfg.maxn, cfg.maxm, pre_t, po);
+            myfr = prefilter32(act, refb.at(r_off, fwd ? 1 : -1), fwd ? ref_len - r_off : r_off + 1,
+                               readb.at(s_off, fwd ? 1 : -1), s_len, cfg.R, cfg.maxn, cfg.maxm, pre_t, po);
         }
         for (uint32_t hh = 0; hh < ng; ++hh) {
             if (__builtin_amdgcn_readlane(myfr, (int)hh)) { ++st.npairs; continue; }   // failed within its first 32 rows
             const int hit = __builtin_amdgcn_readlane(myhit, (int)hh);
             const int r_off = fwd ? hit : hit + 15;                    // spaced_seed.cpp:285
             const int r_len = fwd ? ref_len - r_off : r_off + 1;       // ref_seq.h:284-285
-            PackedFetch fa{ref, r_off, fwd ? 1 : -1};                  // a = reference (ref_seq.h:264)
-            PackedFetch fb{rseq, s_off, fwd ? 1 : -1};
+            const PackedFetch fa = refb.at(r_off, fwd ? 1 : -1);       // a = reference (ref_seq.h:264)
+            const PackedFetch fb = readb.at(s_off, fwd ? 1 : -1);
             AlnOut o;
             align_dispatch<NB>(fa, r_len, fb, s_len, cfg, lds, o);
             if (o.rc == PBA_RC_UNCERTIFIED) { st.redo = 1; return true; }
@@ -477,9 +506,8 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const 
     const uint32_t slot = next_slot(queue);
     if (slot >= n) break;
     const uint32_t r = ids ? ids[slot] : slot;
-    const uint8_t *ref = Rf.packed + Rf.off[rseq_id];
+    const PackedFetch ref = fetch_of(Rf, rseq_id, 0, 1), rseq = fetch_of(Rd, r, 0, 1);
     const int ref_len = (int)Rf.len[rseq_id];
-    const uint8_t *rseq = Rd.packed + Rd.off[r];
     const int slen = (int)Rd.len[r];
     SsState st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int fj = -1;
@@ -613,9 +641,33 @@ static int seqs_alloc(pba_ctx *ctx, pba_seqs *s, uint64_t packed_bytes) {
     return PBA_OK;
 }
 
+// the bit planes of a set whose packed bytes, offsets and lengths are on the device (enqueued on the ctx's stream)
+static int seqs_planes(pba_ctx *ctx, pba_seqs *s) {
+    std::vector<uint64_t> poff(s->n + 1);
+    uint64_t w = 0;
+    for (uint32_t i = 0; i < s->n; ++i) { poff[i] = w; w += ((uint64_t)s->h_len[i] + 31) / 32; }
+    poff[s->n] = w;
+    s->plane_words = w + 2 * kPlaneSlack;
+    HIPCHK(hipMalloc((void **)&s->d_planes, s->plane_words * 2 * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(s->d_planes, 0, s->plane_words * 2 * sizeof(uint32_t), ctx->stream));
+    HIPCHK(hipMalloc((void **)&s->d_poff, sizeof(uint64_t) * (s->n + 1)));
+    HIPCHK(hipMemcpyAsync(s->d_poff, poff.data(), sizeof(uint64_t) * (s->n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (w) {
+        const uint64_t blocks = (w + 255) / 256;
+        if (blocks > 0x7FFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "sequence set too large");
+        hipLaunchKernelGGL(k_make_planes, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, s->d_packed, s->d_off, s->d_len,
+                           s->d_poff, s->n, w, s->d_planes + kPlaneSlack, s->plane_words);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // poff (host vector) must outlive the copy
+    return PBA_OK;
+}
+
 void pba_seqs_destroy(pba_seqs *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
+    if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->d_poff) (void)hipFree(s->d_poff);
     if (s->d_alloc) (void)hipFree(s->d_alloc);
     if (s->d_off) (void)hipFree(s->d_off);
     if (s->d_len) (void)hipFree(s->d_len);
@@ -627,7 +679,7 @@ static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff
                      int strict, pba_seqs **out) {
     pba_seqs *s = new (std::nothrow) pba_seqs();
     if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
-    s->ctx = ctx; s->n = n; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->ctx = ctx; s->n = n; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr; s->d_planes = nullptr; s->d_poff = nullptr; s->plane_words = 0;
     s->h_off.resize(n + 1); s->h_len.resize(n + 1);
     uint64_t pk = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -662,6 +714,8 @@ static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff
     if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "k_pack_text", e); }
     if (strict && h_bad) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_ALPHABET, "pba_seqs_from_text"); }
     s->non_acgt = h_bad != 0;
+    st = seqs_planes(ctx, s);
+    if (st != PBA_OK) { pba_seqs_destroy(s); return st; }
     *out = s;
     return PBA_OK;
 }
@@ -704,7 +758,7 @@ int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, ui
     pba_open_binary(file, file_len, min_excl, max_excl, recs.data(), kept, nullptr);
     pba_seqs *s = new (std::nothrow) pba_seqs();
     if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
-    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr;
+    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr; s->d_planes = nullptr; s->d_poff = nullptr; s->plane_words = 0;
     s->h_off.resize(kept + 1); s->h_len.resize(kept + 1);
     for (size_t i = 0; i < kept; ++i) {
         uint32_t L;
@@ -729,6 +783,8 @@ int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, ui
     if (e == hipSuccess) e = hipMemcpyAsync(s->d_len, s->h_len.data(), sizeof(uint32_t) * (kept + 1), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "pba_seqs_from_records", e); }
+    const int stp = seqs_planes(ctx, s);
+    if (stp != PBA_OK) { pba_seqs_destroy(s); return stp; }
     *out = s;
     return PBA_OK;
 }
