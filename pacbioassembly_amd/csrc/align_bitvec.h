@@ -339,7 +339,11 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
 
     // ------------------------------------------------------------------ phase 2: goal row right of the diagonal
     const bool owner = s_cur == s_m;             // the lane holding row m
+    const int own_lane = s_m & (PBA_WAVE - 1);
     for (int tb = t1 + 1; tb <= t_end;) {
+        // D(m,j) >= j - m: once the column is that far right of the diagonal no later cell can undercut the minimum
+        // (the goal scan takes strict minima only, seq_aligner.h:202-211)
+        if (tb - s_m - m >= __builtin_amdgcn_readlane(best, own_lane)) break;
         const int k0 = (tb - 1) & 31;            // phase 2 starts inside a chunk whose planes are already loaded
         if (k0 == 0) load_text(tb);
         const int kend = min(32, k0 + (t_end - tb + 1));
@@ -375,7 +379,6 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     // v_readlane: the results are wave-uniform and the compiler must know it, or every loop that depends on
     // them (the callers' candidate walks, and through their lengths this function's own step loop) is treated
     // as divergent and its counters and bounds move from SGPRs into VGPRs
-    const int own_lane = s_m & (PBA_WAVE - 1);
     best_out = __builtin_amdgcn_readlane(best, own_lane);
     bestj_out = __builtin_amdgcn_readlane(bestj, own_lane);
     return 0;
