@@ -321,9 +321,37 @@ def _overlap_all_probes(self, reads, d_entries_ptr, n_slots, mask, R, max_trial=
     return out[:min(int(n.value), cap)], {k: getattr(st, k) for k, _ in _lib.PbaOverlapStats._fields_}
 
 
+def _overlap_all_sharded(self, reads, mask, R, max_trial=32, overlap_min=64, targets_per_call=10000, kernel=PBA_KERNEL_AUTO,
+                         cap_per_target=None):
+    """pba_overlap_all for read sets whose candidate lists do not fit one call (false candidates grow with the square of
+    the read count; a call takes at most 2^32): the probe table is built once on the device, the targets go through in
+    ranges.  Same result as one call (the ranges are independent: this is also what ranks of a multi-GPU run do)."""
+    import torch
+    n = reads.count
+    slots = n * 2 * max_trial
+    probes = torch.full((max(slots, 1),), -1, dtype=torch.int64, device="cuda")
+    self.overlap_probes(reads, 0, n, mask, max_trial, probes.data_ptr(), slots)
+    torch.cuda.synchronize()
+    parts, total = [], None
+    for lo in range(0, n, targets_per_call):
+        hi = min(n, lo + targets_per_call)
+        cap = (hi - lo) * (cap_per_target or max(n - 1, 1))
+        ov, st = self.overlap_all_probes(reads, probes.data_ptr(), probes.numel(), mask, R, max_trial, overlap_min, lo, hi, kernel, cap)
+        parts.append(ov)
+        if total is None:
+            total = dict(st)
+        else:
+            for k in ("n_candidates", "n_pairs", "n_overlaps", "n_redo", "scan_ms", "sort_ms", "walk_ms"):
+                total[k] += st[k]
+            total["wide_first"] = max(total["wide_first"], st["wide_first"])
+    out = np.concatenate(parts) if parts else np.zeros(0, OVERLAP_DTYPE)
+    return out, (total or {})
+
+
 Context.overlap_all = _overlap_all
 Context.overlap_probes = _overlap_probes
 Context.overlap_all_probes = _overlap_all_probes
+Context.overlap_all_sharded = _overlap_all_sharded
 
 
 class SeqSet:

@@ -608,6 +608,9 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     torch.cuda.synchronize()
     got2, st2 = ctx.overlap_all_probes(S, gathered.data_ptr(), gathered.numel(), mask, 0.30, 32, 64, kernel=kernel)
     assert [tuple(int(x) for x in r) for r in got2] == want and st2["n_probe_entries"] == st["n_probe_entries"]
+    # target ranges against one probe table built once (how configs 4-5 stay below 2^32 candidates per call)
+    got3, st3 = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=17, kernel=kernel)
+    assert [tuple(int(x) for x in r) for r in got3] == want and st3["n_pairs"] == st["n_pairs"]
 
 
 def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):

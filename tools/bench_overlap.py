@@ -12,6 +12,7 @@ ap.add_argument("--read-len", type=int, default=15000)
 ap.add_argument("--coverage", type=float, default=20.0)
 ap.add_argument("--R", type=float, default=0.30)
 ap.add_argument("--trials", type=int, default=32)
+ap.add_argument("--targets-per-call", type=int, default=0, help="> 0: go through the targets in ranges (one probe table)")
 a = ap.parse_args()
 L = int(a.reads * a.read_len / a.coverage)
 ctx = Context(0)
@@ -22,7 +23,10 @@ mask = eng.mask_from_pattern("111*11*11*1*1111")
 cap = a.reads * 400
 ctx.overlap_all(S, mask, a.R, a.trials, 64, t_lo=0, t_hi=min(64, a.reads), cap=cap)       # warm-up
 t = time.perf_counter()
-ov, st = ctx.overlap_all(S, mask, a.R, a.trials, 64, cap=cap)
+if a.targets_per_call > 0:
+    ov, st = ctx.overlap_all_sharded(S, mask, a.R, a.trials, 64, targets_per_call=a.targets_per_call, cap_per_target=400)
+else:
+    ov, st = ctx.overlap_all(S, mask, a.R, a.trials, 64, cap=cap)
 dt = time.perf_counter() - t
 print(json.dumps({"workload": f"all-vs-all, {a.reads} x {a.read_len} reads @15%, genome {L} ({a.coverage}x), R={a.R}, {a.trials} trials/end",
                   "seconds": round(dt, 3), "overlaps": int(st["n_overlaps"]), "pairs": int(st["n_pairs"]),
