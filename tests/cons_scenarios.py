@@ -131,3 +131,19 @@ def multi_rounds(round_fn, masks, n_reads):
             if nfailure == len(masks):
                 break
     return found_round, log, final
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the stock `locator` command line (locator.cpp): contig file + seed pattern + reads on stdin, R = 0.15
+LOCATOR_CLI = dict(genome_seed=41, genome_len=100000, reads_seed=42, n_reads=400, read_len=2000, err=(0.02, 0.02, 0.02),
+                   pattern="111*11*11*1*1111")
+
+
+def locator_cli_inputs():
+    """(contig text, list of read texts): every 7th read is cut below 500 bases (skipped without an id)."""
+    m = LOCATOR_CLI
+    g = eng.synth_genome(m["genome_seed"], m["genome_len"])
+    reads, offs, _ = eng.synth_reads(m["reads_seed"], g, m["n_reads"], m["read_len"], *m["err"])
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(m["n_reads"])]
+    texts = [t[:300 + 10 * (i % 13)] if i % 7 == 3 else t for i, t in enumerate(texts)]
+    return g.tobytes(), texts

@@ -865,3 +865,27 @@ def test_overlap_all_with_tandem_repeats(ctx, oracle):
         assert [tuple(int(x) for x in r) for r in got] == want, kernel
         assert st["n_pairs"] == pairs and st["n_candidates"] > 20 * st["n_pairs"] / 10
     assert len(want) > 100 and pairs > 3000
+
+
+def test_locator_gpu_example_prints_what_the_reference_locator_prints(lib, tmp_path):
+    """examples/locator_gpu.cpp (the reference's `locator` command line over the C ABI, plain g++) against the stdout of
+    the reference's own main, compiled unmodified and run on the same files (tests/golden/locator_cli.json): same TSV,
+    columns 1-4, including the ids that skip the reads shorter than 500 bases."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from cons_scenarios import LOCATOR_CLI, locator_cli_inputs
+    gold = gold_json("locator_cli.json")
+    out = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "locator_gpu")
+    libdir = os.path.join(ROOT, "pacbioassembly_amd", "lib")
+    subprocess.run(["g++", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "examples", "locator_gpu.cpp"), "-L", libdir, "-lpba", f"-Wl,-rpath,{libdir}"], check=True)
+    contig, texts = locator_cli_inputs()
+    cf = tmp_path / "contig.txt"
+    cf.write_bytes(contig + b"\n")
+    r = subprocess.run([exe, str(cf), LOCATOR_CLI["pattern"]], input=b"\n".join(texts) + b"\n", capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    rows = [[int(x) for x in line.split()] for line in r.stdout.decode().splitlines()]
+    assert rows == gold["rows"] and len(rows) > 250

@@ -182,3 +182,17 @@ def test_spaced_multi_golden(oracle):
     for r, (a, b) in enumerate(zip(final, gold["final"])):
         assert a[0] == b[0] and (not a[0] or a == b), r
     assert sum(1 for x in found_round if x) > 100 and len({x for x in found_round}) >= 5
+
+
+def test_locator_cli_golden(oracle):
+    """The stdout of the reference's own `locator` main, unmodified (tests/golden/locator_cli.json: contig file, pattern,
+    reads on stdin, R = 0.15, its seq_aligner<40000,6000>): the oracle's locator driver prints the same rows."""
+    from cons_scenarios import LOCATOR_CLI, locator_cli_inputs
+    gold = gold_json("locator_cli.json")
+    contig, texts = locator_cli_inputs()
+    reads = np.frombuffer(b"".join(texts), np.uint8)
+    offs = np.cumsum([0] + [len(t) for t in texts]).astype(np.uint64)
+    rows, st = oracle.locator(np.frombuffer(contig, np.uint8), oracle.mask_from_pattern(LOCATOR_CLI["pattern"]), 0.15, reads, offs,
+                              50, 500, maxn=40000, maxm=6000, nthreads=4)
+    got = [[int(r["nseq"]), int(r["pos"]), int(r["cost"]), int(r["seglen"])] for r in rows if r["found"]]
+    assert got == gold["rows"] and len(got) > 250
