@@ -17,7 +17,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpba.so")
 
 SOURCES = ["pba_device.hip", "pba_codec.cpp", "pba_synth.cpp"]
-HEADERS = ["dev_common.h", "align_rowsweep.h", "align_bitvec.h", "align_bvtrace.h", "seed_index.h", "overlap.h", "pba_internal.h"]
+HEADERS = ["dev_common.h", "align_rowsweep.h", "align_bitvec.h", "align_bvtrace.h", "prefilter.h", "consensus.h", "seed_index.h",
+           "overlap.h", "pba_internal.h"]
 
 
 def _hipcc() -> str:
