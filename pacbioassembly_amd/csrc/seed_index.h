@@ -56,8 +56,23 @@ __device__ __forceinline__ void ix_find(const IndexDev &ix, uint32_t key, uint32
     const uint32_t p = ix_part(key, ix.logP);
     const uint32_t lo = ix.part_off[p], hi = ix.part_off[p + 1];
     beg = ix_lower_bound(ix.ent, lo, hi, (uint64_t)key << 32);
-    const uint32_t end = key == 0xFFFFFFFFu ? hi : ix_lower_bound(ix.ent, beg, hi, (uint64_t)(key + 1) << 32);
-    cnt = end - beg;
+    // the end of the run: almost always 0-2 entries further on, so gallop from `beg` (1, 2, 4, ... entries) and finish with
+    // a binary search inside the last stride -- a second full-depth search would double the dependent loads of a probe
+    uint32_t a = beg, step = 1;
+    while (a < hi && (uint32_t)(ix.ent[a] >> 32) == key) {
+        const uint32_t nxt = a + step < hi ? a + step : hi;
+        if (nxt < hi && (uint32_t)(ix.ent[nxt] >> 32) == key) { a = nxt; step <<= 1; }
+        else {                                   // the run ends in (a, nxt]
+            uint32_t l = a + 1, h = nxt;
+            while (l < h) {
+                const uint32_t mid = l + ((h - l) >> 1);
+                if ((uint32_t)(ix.ent[mid] >> 32) == key) l = mid + 1; else h = mid;
+            }
+            a = l;
+            break;
+        }
+    }
+    cnt = a - beg;
 }
 
 // One scan segment: positions [lo, hi) of a sequence, visited ascending (ord = ord0 + pos - lo)
