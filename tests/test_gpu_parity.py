@@ -889,3 +889,16 @@ def test_locator_gpu_example_prints_what_the_reference_locator_prints(lib, tmp_p
     assert r.returncode == 0, r.stderr.decode()
     rows = [[int(x) for x in line.split()] for line in r.stdout.decode().splitlines()]
     assert rows == gold["rows"] and len(rows) > 250
+
+
+def test_locate_random_configs_vs_oracle():
+    """tools/stress_locate.py: random genome sizes, ragged read lengths, error mixes up to the acceptance limit, R from 0.1
+    to 0.45, 10 or 50 probe offsets, both kernels -- rows and counted pairs / cells equal the oracle's."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_locate.py"), "--rounds", "4", "--seed", "5"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("same=True") == 4
