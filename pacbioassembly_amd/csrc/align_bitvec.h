@@ -15,9 +15,12 @@
 // (Pv, Mv); one text column updates the block with ~20 integer ops, i.e. 32 DP cells per
 // ~20 lane-ops instead of ~8 ops per cell.
 //
-// Mapping to the wavefront.  Rows (the shorter sequence, m of them) are cut into superblocks of
-// NB*32 rows; superblock s lives in lane s mod 64 and processes column j at step t = j + s, so
-// a column flows down the lanes one lane per step.  The horizontal deltas leaving the bottom row
+// Mapping to the wavefront.  Rows are the LONGER sequence (as far down as the window reaches: m + w of
+// them), columns the shorter one (m): the free end of the alignment then runs down the last column,
+// whose cells are produced by the last ~w/RB superblocks while the lanes above still work -- with the
+// shorter sequence as rows the same cells cost w extra steps at the end with most of the array idle.
+// Rows are cut into superblocks of NB*32 rows; superblock s lives in lane s mod 64 and processes column
+// j at step t = j + s, so a column flows down the lanes one lane per step.  The horizontal deltas leaving the bottom row
 // of a superblock are carry-outs of v_addc_co_u32, i.e. lane masks in SGPR pairs, and reach the
 // next lane through a scalar 64-bit rotate of those masks (no DPP, no VALU).  Only columns within
 // w of the superblock's rows are processed (lo..hi); cells left of the window are taken as "+1
@@ -124,8 +127,8 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
     return d;
 }
 
-// One sweep over the window [i - wleft, i + w].  Returns 0 when all diagonal checks pass (then best / bestj hold the
-// goal-row minimum and its column), else the first failing row.
+// One sweep over the window [i - wleft, i + w].  Returns 0 when all diagonal checks pass (then best / besti hold the
+// minimum of the last column at or below the diagonal and its row), else the first failing row.
 //
 // Instruction budget (measured on MI355X, tools/ubench_ops: and/or/xor/add/sub/not/bitop3/ashr issue every
 // ~2.5 cycles per SIMD, shifts, bfe, alignbit, lshl_or, add3, addc and DPP moves every ~4.3): a Myers block is
@@ -141,19 +144,21 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 //            parent is not diagonal (INSERT is tried first and wins the tie, seq_aligner.h:167-173)
 // at tr[((t-1) * NB + nb) * 128 + 2 * lane + word]: one 8-byte store per lane, 512 contiguous bytes per instruction.
 template <int NB, bool TRACE = false>
-__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, const PackedFetch &colsF, int n, int wleft, int w,
-                                           double R, int &best_out, int &bestj_out, uint32_t *tr = nullptr,
+__device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
+                                           double R, int &best_out, int &besti_out, uint32_t *tr = nullptr,
                                            bool swap_roles = false) {
+    // rowsF / nr: the longer sequence and how many of its rows are swept (m <= nr <= m + wleft); colsF / m: the shorter
+    // one.  Row i sees the columns [i - wleft, i + w] (wleft: the wide side, towards the free end; w: the narrow one).
     constexpr int RB = 32 * NB;                 // rows per superblock
     const int lane = threadIdx.x & (PBA_WAVE - 1);
-    m = __builtin_amdgcn_readfirstlane(m); n = __builtin_amdgcn_readfirstlane(n);   // wave-uniform by construction
+    m = __builtin_amdgcn_readfirstlane(m); nr = __builtin_amdgcn_readfirstlane(nr);   // wave-uniform by construction
     w = __builtin_amdgcn_readfirstlane(w); wleft = __builtin_amdgcn_readfirstlane(wleft);
-    const int S = (m + RB - 1) / RB;            // superblocks
-    const int s_m = S - 1;                      // superblock, block and bit of row m
+    const int S = (nr + RB - 1) / RB;           // superblocks
+    const int s_m = (m - 1) / RB;               // superblock, block and bit of row m (the end of the diagonal)
     const int nb_m = ((m - 1) - s_m * RB) >> 5, r_m = (m - 1) & 31;
-    const int hi_last = min(n, s_m * RB + RB + w);
     const int t1 = m + s_m;                     // step at which cell (m,m) is produced
-    const int t_end = hi_last + s_m;
+    const int t_end = m + S - 1;                // step at which the last superblock takes the last column
+    (void)nb_m; (void)r_m;
 
     uint32_t Pv[NB], Mv[NB], Plo[NB], Phi[NB], acc[NB];
     int s_cur = lane;
@@ -169,12 +174,14 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         const int base_row = s_cur * RB;
         opened = 0;
         if (s_cur < S) {
-            const int lo = max(1, base_row + 1 - wleft), hi = min(n, base_row + RB + w);
+            const int lo = max(1, base_row + 1 - wleft), hi = min(m, base_row + RB + w);
             t_evt = lo + s_cur;
             t_close1 = hi + s_cur + 1;
-            t_hin_end = s_cur > 0 ? base_row + w + s_cur : INT_MIN;
-            t_diag0 = t_dstart = base_row + 1 + s_cur;
-            t_seg = min(t_diag0 + 31, m + s_cur);
+            t_hin_end = s_cur > 0 ? min(m, base_row + w) + s_cur : INT_MIN;
+            if (base_row < m) {                 // the diagonal (rows 1..m) crosses this superblock
+                t_diag0 = t_dstart = base_row + 1 + s_cur;
+                t_seg = min(t_diag0 + 31, m + s_cur);
+            } else { t_diag0 = INT_MAX - RB; t_dstart = INT_MAX; t_seg = INT_MAX - 1; }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) load_planes32(rowsF, base_row + 32 * nb, Plo[nb], Phi[nb]);
         } else {                                // nothing left for this lane
@@ -187,7 +194,13 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; acc[nb] = 0u; }
 
     uint32_t wl = 0, wh = 0;                     // text bit planes: bit k = low / high bit of the element of step tb+k
-    int score = 0, best = INT_MAX, bestj = 0, fail_row = 0;
+    int score = 0, best = INT_MAX, fail_row = 0;
+    // the vertical deltas of the LAST column as this lane's last superblock at or below row m left them (a lane keeps
+    // stepping on garbage after its window has closed, so they are put aside at the close); fin_s: that superblock, or -1
+    uint32_t fin_pv[NB], fin_mv[NB];
+    int fin_s = -1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { fin_pv[nb] = 0u; fin_mv[nb] = 0u; }
     uint32_t dmw = 0;                            // one-hot: bit of the diagonal cell in its block's word (0: not in this lane)
     uint64_t hp_last = ~0ull, hn_last = 0ull;    // lane masks: delta +1 / -1 leaving each lane's last block in the previous step
     // lanes whose first block still receives the lane above's hout (the others see "+1 per column")
@@ -220,7 +233,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         score = end;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = 0;     // the next block's word starts clean
-        if (i == m) { best = score; bestj = m; }
+        if (i == m) best = score;                        // D(m,m): where the scan down the last column starts
         if (i == m || rr == RB - 1) { t_seg = INT_MAX - 1; dmw = 0; }         // the diagonal leaves this lane's rows
         else t_seg = min(t_seg + 32, m + s_cur);
     };
@@ -235,7 +248,13 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
             /* a lane that moves on to its next superblock needs that superblock's slice of the text; a lane that \
                opens its first window already got its planes at the start of the chunk (no load, no wait: during  \
                the ramp one lane opens per step, and false candidates are all ramp) */                              \
-            if (opened) { s_cur += PBA_WAVE; open_superblock(); load_text(t - ((t - 1) & 31)); } \
+            if (opened) {                                                             \
+                if (s_cur >= s_m) {          /* its window ended with the last column: keep that column */ \
+                    fin_s = s_cur;                                                    \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { fin_pv[nb] = Pv[nb]; fin_mv[nb] = Mv[nb]; } \
+                }                                                                     \
+                s_cur += PBA_WAVE; open_superblock(); load_text(t - ((t - 1) & 31));  \
+            }                                                                         \
             if (t == t_evt) {                                                         \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; } \
                 opened = 1;                                                           \
@@ -337,13 +356,8 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
     t_seg = INT_MAX - 1; t_dstart = INT_MAX;
     t_next = min(t_evt, t <= t_hin_end ? t_hin_end + 1 : INT_MAX);
 
-    // ------------------------------------------------------------------ phase 2: goal row right of the diagonal
-    const bool owner = s_cur == s_m;             // the lane holding row m
-    const int own_lane = s_m & (PBA_WAVE - 1);
+    // ------------------------------------------------------------------ phase 2: the superblocks below row m take the last column
     for (int tb = t1 + 1; tb <= t_end;) {
-        // D(m,j) >= j - m: once the column is that far right of the diagonal no later cell can undercut the minimum
-        // (the goal scan takes strict minima only, seq_aligner.h:202-211)
-        if (tb - s_m - m >= __builtin_amdgcn_readlane(best, own_lane)) break;
         const int k0 = (tb - 1) & 31;            // phase 2 starts inside a chunk whose planes are already loaded
         if (k0 == 0) load_text(tb);
         const int kend = min(32, k0 + (t_end - tb + 1));
@@ -352,23 +366,17 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
         PBA_BV_RARE((void)0);
         const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
         PBA_BV_HIN();
-        uint32_t ph_m = 0, mh_m = 0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             uint32_t d0, php, mhp, eq;
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
-            (void)d0; (void)eq;
-            if (nb == nb_m) { ph_m = php; mh_m = mhp; }
+            (void)d0; (void)eq; (void)php; (void)mhp;
             if constexpr (TRACE) {           // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
                 if (st_on)                   // inside its window (masking lane by lane was measured 1.5x SLOWER: partial lines)
                     PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);
             }
         }
         hp_last = hp; hn_last = hn;
-        if (owner) {                             // D(m,j) = D(m,j-1) + horizontal delta at row m (seq_aligner.h:202-211)
-            score += (int)((ph_m >> r_m) & 1u) - (int)((mh_m >> r_m) & 1u);
-            if (score < best) { best = score; bestj = t - s_m; }
-        }
         }
         tb += kend - k0;
     }
@@ -376,11 +384,47 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int m, cons
 #undef PBA_BV_TRP
 #undef PBA_BV_HIN
 #undef PBA_BV_RARE
+    // ------------------------------------------------------------------ the free end: first strict minimum down the last column
+    // D(i,m) = D(m,m) + the vertical deltas of column m over rows m+1..i (seq_aligner.h:192-211 scans exactly these cells,
+    // upward from the diagonal, and keeps the first strict minimum).  A lane whose window is still open holds the
+    // column in Pv / Mv, the others put it aside when their window closed.
+    if (opened && s_cur >= s_m && s_cur < S) {
+        fin_s = s_cur;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { fin_pv[nb] = Pv[nb]; fin_mv[nb] = Mv[nb]; }
+    }
+    int b_tot[NB], b_min[NB], b_pos[NB];          // per block of this lane's last superblock: sum, lowest prefix sum, its bit
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row0 = fin_s * RB + nb * 32;    // bit r is row row0 + r + 1
+        int v = 0, pm = INT_MAX, pp = 0;
+        for (int r = 0; r < 32; ++r) {
+            const int row = row0 + r + 1;
+            if (fin_s >= 0 && row > m && row <= nr) {
+                v += (int)((fin_pv[nb] >> r) & 1u) - (int)((fin_mv[nb] >> r) & 1u);
+                if (v < pm) { pm = v; pp = r; }
+            }
+        }
+        b_tot[nb] = v; b_min[nb] = pm; b_pos[nb] = pp;
+    }
     // v_readlane: the results are wave-uniform and the compiler must know it, or every loop that depends on
     // them (the callers' candidate walks, and through their lengths this function's own step loop) is treated
     // as divergent and its counters and bounds move from SGPRs into VGPRs
-    best_out = __builtin_amdgcn_readlane(best, own_lane);
-    bestj_out = __builtin_amdgcn_readlane(bestj, own_lane);
+    int gbest = __builtin_amdgcn_readlane(best, s_m & (PBA_WAVE - 1)), gi = m, run = gbest;   // D(m,m)
+    for (int sb = s_m; sb < S; ++sb) {
+        const int L = sb & (PBA_WAVE - 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pm = __builtin_amdgcn_readlane(b_min[nb], L);
+            if (pm != INT_MAX && run + pm < gbest) {
+                gbest = run + pm;
+                gi = sb * RB + nb * 32 + __builtin_amdgcn_readlane(b_pos[nb], L) + 1;
+            }
+            run += __builtin_amdgcn_readlane(b_tot[nb], L);
+        }
+    }
+    best_out = gbest;
+    besti_out = gi;
     return 0;
 }
 
@@ -420,25 +464,26 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
     if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return;      // seq_aligner.h:104-107
-    const bool swap = len_a > len_b;            // the DP is symmetric under transposition: rows = shorter side
-    const int m = swap ? len_b : len_a, n = swap ? len_a : len_b;
+    const bool a_rows = len_a > len_b;          // the DP is symmetric under transposition: rows = the LONGER side
+    const int m = a_rows ? len_b : len_a, n = a_rows ? len_a : len_b;
     if (m <= 10) {                              // no diagonal check ever fires: plain DP on a <= 23-cell band
         align_rowsweep(fa, la, fb, lb, R, maxn, maxm, lds, lds_cells, o);
         return;
     }
+    // w: towards the free end (below the diagonal now that the longer side runs down the rows), wl: the other side
     const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
     if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
-    const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
-    int best = 0, bestj = 0;
-    const int fr = bitvec_pass<NB>(rowsF, m, colsF, n, wl, w, R, best, bestj);
+    const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
+    int best = 0, besti = 0;
+    const int fr = bitvec_pass<NB>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti);
     if (fr) {
         if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return;
     }
     if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return; }   // header comment
     o.cost = best;
-    o.matlen_a = swap ? bestj : m;
-    o.matlen_b = swap ? m : bestj;
+    o.matlen_a = a_rows ? besti : m;
+    o.matlen_b = a_rows ? m : besti;
     o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114
 }
 

@@ -24,12 +24,13 @@
 
 #include "align_bitvec.h"
 
-// scratch words a traced pass needs: steps * NB blocks * 2 words * 64 lanes
+// scratch words a traced pass needs: steps * NB blocks * 2 words * 64 lanes (m columns, the longer side swept down to
+// row min(n, m + w); the last superblock takes the last column at step m + S - 1)
 __device__ __host__ inline uint64_t bv_trace_words(int nb, int m, int n, int w) {
     const int rb = 32 * nb;
-    const int S = (m + rb - 1) / rb;
-    const long long hi_last = (long long)(S - 1) * rb + rb + w;
-    const long long t_end = (hi_last < n ? hi_last : n) + (S - 1);
+    const long long nr = (long long)m + w < n ? (long long)m + w : n;
+    const long long S = (nr + rb - 1) / rb;
+    const long long t_end = m + S - 1;
     return (uint64_t)(t_end > 0 ? t_end : 0) * (uint64_t)nb * 128u;
 }
 
@@ -117,8 +118,9 @@ __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
     if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return false;      // seq_aligner.h:104-107
-    const bool swap = len_a > len_b;
-    const int m = swap ? len_b : len_a, n = swap ? len_a : len_b;
+    const bool a_rows = len_a > len_b;          // rows = the longer side (align_bitvec.h)
+    const bool swap = !a_rows;                  // the array's rows are the reference's b
+    const int m = a_rows ? len_b : len_a, n = a_rows ? len_a : len_b;
     if (m <= 10) {
         // the row sweep's corner (align_bitvec.h): one parent code per band cell in the scratch area
         const int W = 2 * md + 1;
@@ -137,23 +139,23 @@ __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la
         }
         return true;
     }
-    const PackedFetch rowsF = swap ? fb : fa, colsF = swap ? fa : fb;
+    const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
     const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
-    int best = 0, bestj = 0;
+    int best = 0, besti = 0;
     if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return false; }   // host sizes both
-    const int fr = bitvec_pass<NB, true>(rowsF, m, colsF, n, wl, w, R, best, bestj, scratch, swap);
+    const int fr = bitvec_pass<NB, true>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, scratch, swap);
     if (fr) {
         if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return false;
     }
     if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return false; }
     o.cost = best;
-    o.matlen_a = swap ? bestj : m;
-    o.matlen_b = swap ? m : bestj;
+    o.matlen_a = a_rows ? besti : m;
+    o.matlen_b = a_rows ? m : besti;
     o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114
     if (o.rc < 0 || o.matlen_a < min_matlen_a) return false;
     wave_mem_fence();                                   // the walk reads what other lanes stored
-    int ri = m, cj = bestj;
+    int ri = besti, cj = m;                             // the goal cell in array coordinates: (row of the minimum, last column)
     bv_trace_walk<NB>(scratch, ri, cj, swap, sink);
     // border cells (init_cell): row 0 of the reference's matrix is INSERTs, column 0 DELETEs
     if (swap) {
