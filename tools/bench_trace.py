@@ -41,14 +41,15 @@ assert (out["rc"] > 0).all() and (out["cost"] == hit["cost"]).all()
 nedit = np.array([s.size for s in scripts])
 ms = best[0]
 # parent bits of the cells the sweep processes: 2 words per (column of a superblock's window, block): the algorithmic
-# figure; what is actually stored (whole 128-byte lines of the 16-lane groups with an open window) is the PMC's WRITE_SIZE
+# figure; what is actually stored (whole 128-byte lines of the 16-lane groups with an open window) is the PMC's WRITE_SIZE.
+# Rows are the longer side, swept down to row m + w; row i sees the columns [i - w, i + wl] of the m columns.
 nb = int(prof["nb_first"])
 m = int(np.median(pairs["a_len"])); w = max(md // 2, md * 9 // 16) + 1; wl = w // 2 + 1
-n_cols = min(int(np.median(pairs["b_len"])), m + md)
+n_rows = min(int(np.median(pairs["b_len"])), m + w)
 if nb:
     rb = 32 * nb
-    S = -(-m // rb)
-    cols = sum(min(n_cols, s * rb + rb + w) - max(1, s * rb + 1 - wl) + 1 for s in range(S))
+    S = -(-n_rows // rb)
+    cols = sum(max(0, min(m, s * rb + rb + wl) - max(1, s * rb + 1 - w) + 1) for s in range(S))
     stream = cols * nb * 8
 else:
     stream = (m + 1) * (2 * md + 1)
