@@ -9,35 +9,37 @@
 //   * banded D >= U, and a path that leaves the band |i-j| <= max_dst and comes back to
 //     diagonal offset d costs at least 2*(max_dst+1) - |d|;
 //   * a passing diagonal cell has cost <= floor(i*R) <= max_dst-1, so banded and unbanded
-//     values agree wherever the comparison could go either way, and every goal-row cell that
-//     could be a strict minimum costs less than D(m,m) <= max_dst-1.
+//     values agree wherever the comparison could go either way, and every goal cell (last row or
+//     column past the diagonal) that could be a strict minimum costs less than D(m,m) <= max_dst-1.
 // U is evaluated in Myers/Hyyro vertical-delta encoding: a 32-row block holds +1/-1 bit masks
 // (Pv, Mv); one text column updates the block with ~20 integer ops, i.e. 32 DP cells per
 // ~20 lane-ops instead of ~8 ops per cell.
 //
-// Mapping to the wavefront.  Rows are the LONGER sequence (as far down as the window reaches: m + w of
-// them), columns the shorter one (m): the free end of the alignment then runs down the last column,
-// whose cells are produced by the last ~w/RB superblocks while the lanes above still work -- with the
-// shorter sequence as rows the same cells cost w extra steps at the end with most of the array idle.
-// Rows are cut into superblocks of NB*32 rows; superblock s lives in lane s mod 64 and processes column
-// j at step t = j + s, so a column flows down the lanes one lane per step.  The horizontal deltas leaving the bottom row
-// of a superblock are carry-outs of v_addc_co_u32, i.e. lane masks in SGPR pairs, and reach the
-// next lane through a scalar 64-bit rotate of those masks (no DPP, no VALU).  Only columns within
-// w of the superblock's rows are processed (lo..hi); cells left of the window are taken as "+1
-// per row" and the row above the window as "+1 per column", which are real (if expensive) paths,
-// so everything computed is an upper bound W >= U that equals U whenever U's optimal path stays
-// within |i-j| <= w.
-// The window is asymmetric: wl columns left of the diagonal, w right of it.  Goal cells lie right
-// of the diagonal (j >= m), so a path that leaves on the left must come back: it costs >= 2*wl+2,
-// one that leaves on the right >= w+1.  Hence:
+// Mapping to the wavefront.  Rows are the LONGER sequence (as far down as the window reaches: m + w
+// of them), columns the shorter one (m): the free end of the alignment then runs down the last
+// column, whose cells are produced by the last ~w/RB superblocks while the lanes above still work --
+// with the shorter sequence as rows the same cells cost w extra steps at the end with most of the
+// array idle.  Rows are cut into superblocks of NB*32 rows; superblock s lives in lane s mod 64 and
+// processes column j at step t = j + s, so a column flows down the lanes one lane per step.  The
+// horizontal deltas leaving the bottom row of a superblock are carry-outs of v_addc_co_u32, i.e. lane
+// masks in SGPR pairs, and reach the next lane through a scalar 64-bit rotate of those masks (no DPP,
+// no VALU).  Only the columns of a superblock's window are processed (lo..hi); cells left of the
+// window are taken as "+1 per row" and the row above the window as "+1 per column", which are real
+// (if expensive) paths, so everything computed is an upper bound W >= U that equals U whenever U's
+// optimal path stays inside the windows.
+// The window is asymmetric: row i sees the columns [i - w, i + wl]: w on the side of the free end
+// (below the diagonal, where the goal cells (i, m), i >= m, lie), wl on the other.  A path that leaves
+// on the wl side must come back across the diagonal: it costs >= 2*wl+2; one that leaves on the w
+// side costs >= w+1.  Hence:
 //   * a PASSING diagonal verdict is always exact (W >= U);  a FAILING one at row i is exact when
 //     floor(i*R) < 2*wl+2 (no unseen path back to the diagonal is cheap enough to change it);
-//   * the goal row is exact when its minimum is <= min(w, 2*wl+1).
+//   * the goal column is exact when its minimum is <= min(w, 2*wl+1).
 // Anything else answers "uncertified" and the pair is re-run with w = max_dst, the reference's own
-// band, and wl = max_dst/2 + 1: every row's threshold floor(i*R) <= max_dst - 1 < 2*wl + 2 and every goal
-// minimum of a pair that passed its checks is <= max_dst - 1, so that sweep certifies everything.
-// Results are bit-identical to the reference in all cases.  First pass: w = 9/16 max_dst, wl = w/2: 25 % fewer cells than a symmetric window and,
-// more to the point, narrow enough for one block less per lane at BASELINE sizes.
+// band, and wl = max_dst/2 + 1: every row's threshold floor(i*R) <= max_dst - 1 < 2*wl + 2 and every
+// goal minimum of a pair that passed its checks is <= max_dst - 1, so that sweep certifies
+// everything.  Results are bit-identical to the reference in all cases.  First pass: w = 9/16
+// max_dst, wl = w/2: 25 % fewer cells than a symmetric window and, more to the point, narrow enough
+// for one block less per lane at BASELINE sizes.
 #ifndef PBA_ALIGN_BITVEC_H
 #define PBA_ALIGN_BITVEC_H
 
