@@ -73,18 +73,29 @@ k_ovl_presence(const uint64_t *ent, uint64_t n, uint32_t *bits) {
     atomicOr(bits + (h >> 5), 1u << (h & 31));
 }
 
-// FILL = false: cnt[t - t_lo] = candidates of target t.  FILL = true: write them at cursor[t - t_lo]++.
+// A target's candidates are kept in PBA_OVL_SUB buckets of consecutive queries (bucket = umulhi(q, 2^32 * SUB / n_reads),
+// monotone in q, so the buckets in order are the list in query order): each bucket is counted, filled and sorted on its own, which keeps
+// every sorted piece inside the LDS sort even when a target has far more than 16 384 candidates (57 000 at a million
+// reads).  `shift` merges 2^shift neighbouring buckets (the host picks the coarsest split whose pieces still fit).
+// FILL = false: cnt[(t - t_lo) * SUB + bucket] = candidates.  FILL = true: piece p = bucket >> shift of target t is written
+// from cursor[(t - t_lo) * (SUB >> shift) + p] on.
+#define PBA_OVL_SUB 64
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_ovl_scan(IndexDev probes, const uint32_t *presence, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2,
-           uint32_t *cnt_or_cursor, uint64_t *cand) {
+           uint32_t sub_mul, int shift, uint32_t *cnt_or_cursor, uint64_t *cand) {
     const uint32_t tl = blockIdx.x;
     if (tl >= n_targets) return;
+    // one workgroup owns a target, so its buckets' counters / write cursors live in LDS (a global atomic per candidate on
+    // per-bucket addresses cannot be folded into one per wavefront and was the slowest part of the scan)
+    __shared__ uint32_t sub[PBA_OVL_SUB];
+    if (threadIdx.x < PBA_OVL_SUB)
+        sub[threadIdx.x] = FILL ? (threadIdx.x < (PBA_OVL_SUB >> shift) ? cnt_or_cursor[tl * (PBA_OVL_SUB >> shift) + threadIdx.x] : 0u) : 0u;
+    __syncthreads();
     const uint32_t t = t_lo + tl;
     const int len = (int)Rd.len[t];
     const uint8_t *seq = Rd.packed + Rd.off[t];
     const HeadTail ht(len);
-    uint32_t mine = 0;
     for (int ord = (int)threadIdx.x; ord < ht.visited; ord += (int)blockDim.x) {
         const int pos = ht.pos_of(ord);
         const uint32_t key = window_key(seq, (uint32_t)pos, (uint32_t)len) & probes.mask;
@@ -97,21 +108,18 @@ k_ovl_scan(IndexDev probes, const uint32_t *presence, SeqSetDev Rd, uint32_t t_l
             const uint32_t pid = (uint32_t)probes.ent[beg + h];
             const uint32_t q = pid / t2;
             if (q == t) continue;
+            const uint32_t b = min((uint32_t)PBA_OVL_SUB - 1, __umulhi(q, sub_mul));   // ~ q * SUB / n_reads, monotone in q
             if (FILL) {
-                const uint32_t slot = atomicAdd(&cnt_or_cursor[tl], 1u);
+                const uint32_t slot = atomicAdd(&sub[b >> shift], 1u);
                 cand[slot] = (uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pid % t2) << PBA_OVL_ORD_BITS | (uint32_t)ord;
             } else {
-                ++mine;
+                atomicAdd(&sub[b], 1u);
             }
         }
     }
     if (!FILL) {
-        __shared__ uint32_t total;
-        if (threadIdx.x == 0) total = 0;
         __syncthreads();
-        if (mine) atomicAdd(&total, mine);
-        __syncthreads();
-        if (threadIdx.x == 0) cnt_or_cursor[tl] = total;
+        if (threadIdx.x < PBA_OVL_SUB) cnt_or_cursor[tl * PBA_OVL_SUB + threadIdx.x] = sub[threadIdx.x];
     }
 }
 

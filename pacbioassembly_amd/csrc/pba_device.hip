@@ -1720,40 +1720,76 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
         hipLaunchKernelGGL(k_ovl_presence, dim3((uint32_t)((pix->n_entries + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const uint64_t *)pix->d_ent, (uint64_t)pix->n_entries, d_pres.as<uint32_t>());
     HIPCHK(hipMalloc(&d_off.p, sizeof(uint32_t) * (nt + 1)));
-    HIPCHK(hipMalloc(&d_cur.p, sizeof(uint32_t) * (nt + 1)));
+    // count per (target, bucket of consecutive queries): PBA_OVL_SUB buckets per target
+    const uint64_t nsub = (uint64_t)nt * PBA_OVL_SUB;
+    const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // bucket = umulhi(q, sub_mul)
+    DevBuf d_sub;
+    HIPCHK(hipMalloc(&d_sub.p, sizeof(uint32_t) * (nsub + 1)));
     hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), d_pres.as<uint32_t>(), reads->dev(),
-                       t_lo, nt, t2, d_cur.as<uint32_t>(), (uint64_t *)nullptr);
-    std::vector<uint32_t> h_cnt(nt + 1), h_off(nt + 1);
-    HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cur.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+                       t_lo, nt, t2, sub_mul, 0, d_sub.as<uint32_t>(), (uint64_t *)nullptr);
+    std::vector<uint32_t> h_sub(nsub + 1), h_cnt(nt + 1), h_off(nt + 1);
+    HIPCHK(hipMemcpyAsync(h_sub.data(), d_sub.p, sizeof(uint32_t) * nsub, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
+    // the coarsest split (2^shift neighbouring buckets merged) whose pieces all fit the LDS sort
+    int shift = 0;
+    for (int sh = 6; sh >= 0; --sh) {                            // PBA_OVL_SUB = 2^6
+        bool fits = true;
+        for (uint64_t p0 = 0; p0 < nsub && fits; p0 += (1ull << sh)) {
+            uint64_t c = 0;
+            for (uint64_t k = 0; k < (1ull << sh); ++k) c += h_sub[p0 + k];
+            fits = c <= PBA_IX_LDS_SORT_CAP;
+        }
+        if (fits) { shift = sh; break; }
+    }
+    const uint32_t per_t = PBA_OVL_SUB >> shift;                  // sorted pieces per target
+    const uint64_t npiece = (uint64_t)nt * per_t;
+    std::vector<uint32_t> h_poff(npiece + 1);
     uint64_t total = 0;
-    for (uint32_t i = 0; i < nt; ++i) { h_off[i] = (uint32_t)total; total += h_cnt[i]; }
-    if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: more than 2^32 candidates in one target range; shard it");
+    uint32_t biggest = 2;
+    std::vector<uint32_t> oversize;                               // pieces that outgrow the LDS sort even at the finest split
+    for (uint32_t i = 0; i < nt; ++i) {
+        h_off[i] = (uint32_t)total;
+        for (uint32_t pc = 0; pc < per_t; ++pc) {
+            uint64_t c = 0;
+            for (uint32_t k = 0; k < (1u << shift); ++k) c += h_sub[(uint64_t)i * PBA_OVL_SUB + ((uint64_t)pc << shift) + k];
+            h_poff[(uint64_t)i * per_t + pc] = (uint32_t)total;
+            if (c <= PBA_IX_LDS_SORT_CAP) biggest = std::max<uint32_t>(biggest, (uint32_t)c);
+            else oversize.push_back((uint32_t)((uint64_t)i * per_t + pc));
+            total += c;
+            if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: more than 2^32 candidates in one target range; shard it");
+        }
+        h_cnt[i] = (uint32_t)(total - h_off[i]);
+    }
     h_off[nt] = (uint32_t)total;
+    h_poff[npiece] = (uint32_t)total;
     st.n_candidates = total;
+    DevBuf d_poff;
     HIPCHK(hipMalloc(&d_cand.p, sizeof(uint64_t) * (total + 1)));
+    HIPCHK(hipMalloc(&d_poff.p, sizeof(uint32_t) * (npiece + 1)));
+    HIPCHK(hipMalloc(&d_cur.p, sizeof(uint32_t) * (npiece + 1)));
     HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_cur.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_poff.p, h_poff.data(), sizeof(uint32_t) * (npiece + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_cur.p, h_poff.data(), sizeof(uint32_t) * (npiece + 1), hipMemcpyHostToDevice, ctx->stream));
     if (total) {
         hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), d_pres.as<uint32_t>(),
-                           reads->dev(), t_lo, nt, t2, d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
+                           reads->dev(), t_lo, nt, t2, sub_mul, shift, d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
         (void)hipEventRecord(ctx->ev[3], ctx->stream);
-        // 3. per-target sort = the reference's try order inside every (target, query)
-        uint32_t biggest = 2;
-        for (uint32_t i = 0; i < nt; ++i)
-            if (h_cnt[i] <= PBA_IX_LDS_SORT_CAP) biggest = std::max(biggest, h_cnt[i]);
+        // 3. sort every piece = the reference's try order inside every (target, query); the pieces of a target in
+        //    order are its list in query order
         uint32_t pow2 = 2;
         while (pow2 < biggest) pow2 <<= 1;
-        hipLaunchKernelGGL(k_part_sort, dim3(nt), dim3(256), sizeof(uint64_t) * pow2, ctx->stream, d_cand.as<uint64_t>(),
-                           d_off.as<uint32_t>());
+        for (uint64_t p0 = 0; p0 < npiece; p0 += 0x40000000ull) {  // (grid dimension limit)
+            const uint32_t chunk = (uint32_t)std::min<uint64_t>(npiece - p0, 0x40000000ull);
+            hipLaunchKernelGGL(k_part_sort, dim3(chunk), dim3(256), sizeof(uint64_t) * pow2, ctx->stream, d_cand.as<uint64_t>(),
+                               d_poff.as<uint32_t>() + p0);
+        }
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipGetLastError());
-        for (uint32_t i = 0; i < nt; ++i)
-            if (h_cnt[i] > PBA_IX_LDS_SORT_CAP) {
-                rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], h_cnt[i]);
-                if (rc != PBA_OK) return rc;
-            }
+        for (uint32_t pc : oversize) {                            // e.g. one query with > 16 384 candidates on a target
+            rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_poff[pc], h_poff[pc + 1] - h_poff[pc]);
+            if (rc != PBA_OK) return rc;
+        }
     } else {
         (void)hipEventRecord(ctx->ev[3], ctx->stream);
     }
