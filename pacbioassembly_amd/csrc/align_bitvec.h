@@ -237,7 +237,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
         for (int nb = 0; nb < NB; ++nb) acc[nb] = 0;     // the next block's word starts clean
         if (i == m) best = score;                        // D(m,m): where the scan down the last column starts
         if (i == m || rr == RB - 1) { t_seg = INT_MAX - 1; dmw = 0; }         // the diagonal leaves this lane's rows
-        else t_seg = min(t_seg + 32, m + s_cur);
+        else { t_seg = min(t_seg + 32, m + s_cur); dmw = 1u; }                // ... or enters the lane's next block at its bit 0
     };
 
     // rare, divergent: segment finished last step / window opens now / window closed last step / diagonal enters
@@ -340,7 +340,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
             acc[nb] = or_of_and(acc[nb], d0, dmw);
         }
         hp_last = hp; hn_last = hn;
-        dmw = (dmw << 1) | (dmw >> 31);
+        dmw += dmw;                              // next row of the block (full-rate add; segment_done re-arms it every 32 rows)
         }
     }
     int t = t1 + 1;
