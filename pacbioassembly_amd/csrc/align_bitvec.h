@@ -444,6 +444,19 @@ __device__ __host__ inline int bv_first_wl(int md) {
     const int wl = bv_first_w(md) / 2 + 1;
     return wl > md ? md : wl;
 }
+// The first-pass window of a launch whose lanes hold NB blocks: with NB fixed the number of steps does not depend on the
+// window (lanes that would idle fill up), so it is as wide as the ring lets it be -- the whole band for short pairs,
+// 18 % instead of 16.9 % divergence certified at 15 kb -- at no cost.
+__device__ __host__ inline int bv_pass1_w(int md, int nb) {
+    int w = bv_first_w(md);
+    const int room = (bv_max_span(nb) - 4) * 2 / 3;      // w + (w/2 + 1) <= span
+    if (room > w) w = room;
+    return w > md ? md : w;
+}
+__device__ __host__ inline int bv_pass1_wl(int md, int nb) {
+    const int wl = bv_pass1_w(md, nb) / 2 + 1;
+    return wl > md ? md : wl;
+}
 // the verdicts of a sweep over [i - wl, i + w] (header comment): a failure at row fr / a goal minimum `best`
 __device__ __forceinline__ bool bv_fail_certified(int fr, double R, int wl, int md) {
     return 2 * wl + 2 > md || (double)fr * R < (double)(2 * wl + 2);      // floor(i*R) <= md - 1 for every row
@@ -473,7 +486,7 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
         return;
     }
     // w: towards the free end (below the diagonal now that the longer side runs down the rows), wl: the other side
-    const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
+    const int w = full_band ? md : bv_pass1_w(md, NB), wl = full_band ? bv_full_wl(md) : bv_pass1_wl(md, NB);
     if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
     int best = 0, besti = 0;

@@ -140,7 +140,7 @@ __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la
         return true;
     }
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
-    const int w = full_band ? md : bv_first_w(md), wl = full_band ? bv_full_wl(md) : bv_first_wl(md);
+    const int w = full_band ? md : bv_pass1_w(md, NB), wl = full_band ? bv_full_wl(md) : bv_pass1_wl(md, NB);
     int best = 0, besti = 0;
     if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return false; }   // host sizes both
     const int fr = bitvec_pass<NB, true>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, scratch, swap);

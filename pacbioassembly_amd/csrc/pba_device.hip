@@ -1283,7 +1283,7 @@ static uint64_t trace_words_of(int la, int lb, double R, int nb, bool full_band)
     const int len_a = lb >= la ? la : std::min(la, lb + md), len_b = lb >= la ? std::min(lb, la + md) : lb;
     const int m = std::min(len_a, len_b), n = std::max(len_a, len_b);
     if (m <= 10) return (((uint64_t)len_a + 1) * (2ull * md + 1) + 3) / 4;       // the row sweep's corner: byte codes
-    return bv_trace_words(nb, m, n, full_band ? md : bv_first_w(md));
+    return bv_trace_words(nb, m, n, full_band ? md : bv_pass1_w(md, nb));
 }
 
 struct pba_cons;
