@@ -319,6 +319,33 @@ int pba_spaced_multi(pba_ctx *ctx, const pba_seqs *ref, uint32_t ref_seq, const 
                      const uint32_t *picks, int n_picks, int max_round, pba_ss_row *rows, int32_t *found_round,
                      pba_ss_round_log *log, int log_cap, int *n_rounds);
 
+/* One round of spaced_seed.cpp:420-446 against the UNLOCKED reference c: the reads pool[0..n_pool) in that order, each
+ * walked like spaced_seed.cpp:424-437 (first success over j, forward then backward) with ref_seq::try_align voting and
+ * growing the reference as it goes (ref_seq.h:259-276) -- so a read sees the text as the reads before it left it.  The
+ * seed index is get_seedmap's (ref_seq.h:291-311) over [beg, end) as the round finds it.  maxn / maxm: the size guard of
+ * the caller's aligner (t_aligner: 26000, 6000; 0, 0 = none).  rows[read id] is filled for the reads of the pool.  The
+ * caller calls pba_cons_evolve afterwards (spaced_seed.cpp:451).  Replaces: the loop body of spaced_seed.cpp:410-446
+ * for a reference that is not locked.  Runs as batches on the device (see pba_device.hip); results are those of the
+ * serial loop. */
+typedef struct {
+    int32_t n_found;               /* nmatches, spaced_seed.cpp:434 */
+    int32_t n_batches;             /* launches of the round kernel (1 + one per growth that mattered to a later read) */
+    int32_t n_grown_fwd, n_grown_bwd;   /* append / prepend calls, ref_seq.h:270-273 */
+    uint32_t n_deferred;           /* reads put back behind a growth, summed over the batches */
+    uint32_t n_index;              /* entries of the round's seed index */
+} pba_cons_round_stats;
+int pba_cons_round(pba_ctx *ctx, pba_cons *c, const pba_seqs *reads, const uint32_t *pool, uint32_t n_pool, uint32_t mask,
+                   double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel, int maxn, int maxm,
+                   pba_ss_row *rows, pba_cons_round_stats *stats);
+/* spaced_seed's main loop (spaced_seed.cpp:409-452) WITHOUT -l: pba_cons_round over the reads not found yet, the seed of
+ * a round chosen as in pba_spaced_multi, pba_cons_evolve after every round except one that ends the loop (every seed
+ * failed in a row, spaced_seed.cpp:450).  rows / found_round / log as in pba_spaced_multi; ref_len_log[k] = length of the
+ * reference after round k+1. */
+int pba_cons_assemble(pba_ctx *ctx, pba_cons *c, const pba_seqs *reads, double R, int max_trial, int overlap_min,
+                      int buggy_seed_at, int kernel, int maxn, int maxm, const uint32_t *masks, int n_masks,
+                      const uint32_t *picks, int n_picks, int max_round, pba_ss_row *rows, int32_t *found_round,
+                      pba_ss_round_log *log, int32_t *ref_len_log, int log_cap, int *n_rounds);
+
 /* ------------------------------------------------------------------------ */
 /* All-vs-all overlap.  Not a loop the reference  */
 /* has, but built only from its pieces: every read t in [t_lo, t_hi) takes the */

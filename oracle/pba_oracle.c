@@ -804,6 +804,59 @@ int orc_cons_try(orc_cons *c, orc_aligner *al, int pos, const char *seg_origin, 
     return ok;
 }
 
+/* One UNLOCKED round of spaced_seed.cpp:420-446: the loop of orc_spaced_round, but serial and in pool order, because
+ * pref->try_align (ref_seq.h:259-276) votes and grows the reference as it goes.  The seed map is get_seedmap's over
+ * [beg, end) as the round finds it (spaced_seed.cpp:415).  rows[k] belongs to pool[k].  Returns nmatches. */
+static int cr_try(orc_cons *c, orc_aligner *al, const orc_seedmap *sm, uint32_t mask, double R, int overlap_min, int buggy,
+                  const uint8_t *rec, const char *txt, int seg_len, long pos, int dir, orc_ss_row *row)
+{
+    uint32_t sd = buggy ? orc_seed_at(rec, (int)pos) : orc_seed_at_fixed(rec, (int)pos);
+    const orc_knode *k = sm_find(sm, sd & mask);                    /* spaced_seed.cpp:265 */
+    if (!k) return 0;
+    ++row->n_trials;
+    const int fwd = dir == 1;
+    const int s_off = fwd ? (int)pos : (int)pos + 15;               /* spaced_seed.cpp:274 */
+    const int s_len = fwd ? seg_len - s_off : s_off + 1;            /* spaced_seed.cpp:275 */
+    if (s_len < overlap_min) return 0;                              /* spaced_seed.cpp:280 */
+    for (const orc_pnode *p = k->head; p; p = p->next) {
+        const int r_off = fwd ? p->pos : p->pos + 15;               /* spaced_seed.cpp:285 */
+        int32_t out[8];
+        ++row->n_pairs;
+        if (!orc_cons_try(c, al, r_off, txt + s_off, s_len, fwd, R, overlap_min, out)) continue;   /* spaced_seed.cpp:286 */
+        row->found = 1; row->dir = dir; row->ref_pos = p->pos; row->cost = out[2];
+        row->matlen_a = out[3]; row->matlen_b = out[1];
+        return 1;
+    }
+    return 0;
+}
+
+int orc_cons_round(orc_cons *c, orc_aligner *al, uint32_t mask, double R, int max_trial, int overlap_min, int buggy_seed_at,
+                   const uint8_t *records, const uint64_t *rec_offs, const int32_t *pool, int npool, orc_ss_row *rows)
+{
+    orc_seedmap *sm = orc_seedmap_new((size_t)1 << 20);
+    if (!sm) return -1;
+    orc_index_head_tail(sm, c->txt + c->beg, c->end - c->beg, mask);     /* ref_seq.h:291-311 */
+    char *txt = (char *)malloc(1 << 20);
+    int nmatches = 0;
+    for (int k = 0; k < npool; ++k) {
+        const uint8_t *rec = records + rec_offs[pool[k]];
+        orc_ss_row *row = &rows[k];
+        memset(row, 0, sizeof *row);
+        row->read = pool[k]; row->j = -1;
+        int slen = (int)orc_bin2text(rec, txt, 1 << 20);
+        for (int j = 0; j < max_trial; ++j) {                       /* spaced_seed.cpp:424-426 */
+            if (cr_try(c, al, sm, mask, R, overlap_min, buggy_seed_at, rec, txt, slen, j, 1, row) ||
+                cr_try(c, al, sm, mask, R, overlap_min, buggy_seed_at, rec, txt, slen, (long)slen - j - 16, -1, row)) {
+                row->j = j; ++nmatches;
+                break;
+            }
+        }
+    }
+    free(txt);
+    orc_seedmap_free(sm);
+    return nmatches;
+}
+
 void orc_cons_evolve(orc_cons *c) {
     cbox *nb = (cbox *)calloc((size_t)3 * c->max_len + 64, sizeof(cbox));
     int nn = 0;

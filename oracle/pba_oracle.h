@@ -138,6 +138,11 @@ void      orc_cons_elect(orc_cons *c, int pos, int fwd, const uint8_t *ops, cons
 int       orc_cons_try(orc_cons *c, orc_aligner *al, int pos, const char *seg_origin, int seg_len, int fwd,
                        double R, int overlap_min, int32_t *out);
 void      orc_cons_evolve(orc_cons *c);                                                /* ref_seq.h:317-349 */
+/* one unlocked round of spaced_seed.cpp:420-446 (serial, pool order; try_align votes and grows); rows[k] <-> pool[k];
+ * returns nmatches.  The caller evolves (spaced_seed.cpp:451). */
+int       orc_cons_round(orc_cons *c, orc_aligner *al, uint32_t mask, double R, int max_trial, int overlap_min,
+                         int buggy_seed_at, const uint8_t *records, const uint64_t *rec_offs, const int32_t *pool,
+                         int npool, orc_ss_row *rows);
 /* vote list in list order; extent = {pre-beg, post-beg, end-beg}; returns the number of boxes */
 int       orc_cons_dump(const orc_cons *c, uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *extent);
 int       orc_cons_text(const orc_cons *c, char *out, int cap);                        /* text [pre, post) */

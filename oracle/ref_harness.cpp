@@ -276,6 +276,59 @@ int ref_cons_try(int pos, char *seg_origin, int seg_len, int fwd, double R, int3
 
 void ref_cons_evolve(void) { g_cons->evolve(); }
 
+/* one UNLOCKED round of spaced_seed.cpp:420-446 on g_cons: get_seedmap, then every read of the pool in order through
+ * try_align (spaced_seed.cpp:262-298) with the reference's own ref_seq::try_align (votes, growth) on the stock
+ * t_aligner, OVERLAP_MIN = 64 and the reference's seed_at.  rows[k] <-> pool[k], 10 ints as ref_spaced_round.
+ * Returns nmatches.  `records` must be followed by >= 32 KB of readable bytes. */
+static bool cr_try(hash_table &sm, uint8_t *rec, char *txt, int seg_len, long pos, int dir, uint32_t mask, int32_t *row) {
+    sm_it sit = sm.find(dna_seq::seed_at(rec, (int)pos) & mask);   /* spaced_seed.cpp:265 */
+    if (sit == sm.end()) return false;
+    ++row[8];
+    bool forward = dir == 1;
+    int s_offset = forward ? (int)pos : (int)pos + 16 - 1;
+    int s_len = forward ? seg_len - s_offset : s_offset + 1;
+    seq_accessor ac_seg(txt + s_offset, forward, s_len);
+    if (s_len < OVERLAP_MIN) return false;
+    for (std::list<int>::iterator it = sit->second.begin(); it != sit->second.end(); ++it) {
+        int r_offset = forward ? (*it) : (*it) + 16 - 1;
+        seq_accessor ac_ref = g_cons->get_accessor(r_offset, forward);
+        canonicalise(g_stock, ac_ref.length(), s_len);
+        ++row[9];
+        ac_seg.reset(0);
+        if (g_cons->try_align(g_stock, r_offset, &ac_seg)) {       /* spaced_seed.cpp:286 */
+            row[1] = 1; row[3] = dir; row[4] = *it; row[5] = g_stock->final_cost(); row[6] = g_stock->matlen_a; row[7] = g_stock->matlen_b;
+            return true;
+        }
+    }
+    return false;
+}
+
+int ref_cons_round(uint32_t mask, double R, int max_trial, uint8_t *records, const uint64_t *rec_offs, const int32_t *pool,
+                   int npool, int32_t *rows) {
+    if (!g_stock) g_stock = new t_aligner();
+    g_stock->R = R;
+    hash_table sm(1 << 20);
+    g_cons->get_seedmap(sm, mask);                                  /* spaced_seed.cpp:415 */
+    std::vector<char> txt(1 << 20);
+    int nmatches = 0;
+    for (int k = 0; k < npool; ++k) {
+        uint8_t *rec = records + rec_offs[pool[k]];
+        int32_t *row = rows + 10 * k;
+        memset(row, 0, 10 * sizeof(int32_t));
+        row[0] = pool[k]; row[2] = -1;
+        int slen = (int)dna_seq::bin2text(rec, &txt[0], 1 << 20);
+        for (int j = 0; j < max_trial; ++j) {
+            if (cr_try(sm, rec, &txt[0], slen, j, 1, mask, row) ||
+                cr_try(sm, rec, &txt[0], slen, (long)slen - j - 16, -1, mask, row)) {
+                row[2] = j; ++nmatches;
+                break;
+            }
+        }
+    }
+    return nmatches;
+}
+
+
 /* the vote list in list order: sel[4k..], sup[4k..], tot[k]; returns the number of boxes */
 int ref_cons_dump(uint16_t *sel, uint16_t *sup, int32_t *tot, int cap, int32_t *extent) {
     int n = 0;

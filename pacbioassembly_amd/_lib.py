@@ -111,6 +111,10 @@ SYMBOLS = {
     "pba_cons_prepend": (C.c_int, [_P, _P, C.c_char_p, C.c_int]),
     "pba_cons_elect": (C.c_int, [_P, _P, C.c_uint32, _P, _P, _P, _P, _P, _P]),
     "pba_cons_vote_pairs": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
+    "pba_cons_round": (C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, _P, _P]),
+    "pba_cons_assemble": (C.c_int, [_P, _P, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
+                                    _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "pba_cons_evolve": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "pba_cons_dump": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "pba_cons_text": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),

@@ -445,10 +445,12 @@ __device__ __forceinline__ uint32_t seed_at_dev(const uint8_t *payload, int pos,
 
 struct SsState {
     int found, dir, ref_pos, cost, ma, mb, ntrials, npairs, redo;
+    int touch;      // 1: a forward candidate whose reference accessor ends within reach of the alignment (its outcome depends
+                    // on where the reference text ends: ref_seq.h:268 growth), 2: a backward one (where it begins)
 };
 
 template <int NB>
-__device__ __forceinline__ bool ss_try(const IndexDev &ix, const PackedFetch &refb, int ref_len, const PackedFetch &readb,
+__device__ __forceinline__ bool ss_try(const IndexDev &ix, const PackedFetch &refb, int ref_len, int ref_org, const PackedFetch &readb,
                                        int slen, int pos, int dir, int overlap_min, int buggy, const AlignCfg &cfg,
                                        const PreThresholds &pre_t, void *lds, SsState &st) {
     const uint8_t *rseq = readb.seq;
@@ -466,8 +468,12 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const PackedFetch &re
     for (uint32_t h0 = 0; h0 < cnt; h0 += PBA_WAVE) {                 // 64 hits at a time through the prefilter, then in list order
         const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), ng = min((uint32_t)PBA_WAVE, cnt - h0);
         const bool act = lane < ng;
-        const int myhit = act ? ix_pos_of(ix, (uint32_t)ix.ent[beg + h0 + lane]) : 0;
+        const int myhit = act ? ix_pos_of(ix, (uint32_t)ix.ent[beg + h0 + lane]) + ref_org : 0;   // index positions count from `beg`
         int myfr = 0;
+        {   // seq_aligner.h:94-102: the accessor's own length matters only below len_b + max_dst
+            const int my_rlen = fwd ? ref_len - myhit : myhit + 16;
+            if (__builtin_amdgcn_ballot_w64(act && my_rlen <= s_len + 1 + (int)((double)s_len * cfg.R)) != 0ull) st.touch |= fwd ? 1 : 2;
+        }
         if constexpr (NB != 0) {
             const int r_off = fwd ? myhit : myhit + 15;
             AlnOut po;
@@ -487,16 +493,19 @@ __device__ __forceinline__ bool ss_try(const IndexDev &ix, const PackedFetch &re
             ++st.npairs;
             if (o.rc < 0) continue;                                    // ref_seq.h:264
             if (o.matlen_a < overlap_min) continue;                    // ref_seq.h:265
-            st.found = 1; st.dir = dir; st.ref_pos = hit; st.cost = o.cost; st.ma = o.matlen_a; st.mb = o.matlen_b;
+            st.found = 1; st.dir = dir; st.ref_pos = hit - ref_org; st.cost = o.cost; st.ma = o.matlen_a; st.mb = o.matlen_b;
             return true;
         }
     }
     return false;
 }
 
+// ref_org: where position 0 of the index (ref_seq's `beg`) sits inside Rf[rseq_id] -- 0 for a locked reference; beg - pre
+// when the text is an unlocked reference that has grown before its origin (ref_seq.h:235-242).
+// redo[r]: bit 0 = re-run at the reference band, bits 2:1 = SsState::touch.
 template <int NB>
 __global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
-k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const uint32_t *ids, uint32_t n,
+k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, int ref_org, SeqSetDev Rd, const uint32_t *ids, uint32_t n,
                int max_trial, int overlap_min, int buggy, AlignCfg cfg, pba_ss_row *rows, int *redo, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
@@ -509,11 +518,11 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const 
     const PackedFetch ref = fetch_of(Rf, rseq_id, 0, 1), rseq = fetch_of(Rd, r, 0, 1);
     const int ref_len = (int)Rf.len[rseq_id];
     const int slen = (int)Rd.len[r];
-    SsState st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    SsState st = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int fj = -1;
     for (int j = 0; j < max_trial; ++j) {                          // spaced_seed.cpp:424-426
-        if (ss_try<NB>(ix, ref, ref_len, rseq, slen, j, 1, overlap_min, buggy, cfg, pre_t, lds, st) ||
-            ss_try<NB>(ix, ref, ref_len, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, pre_t, lds, st)) {
+        if (ss_try<NB>(ix, ref, ref_len, ref_org, rseq, slen, j, 1, overlap_min, buggy, cfg, pre_t, lds, st) ||
+            ss_try<NB>(ix, ref, ref_len, ref_org, rseq, slen, slen - j - 16, -1, overlap_min, buggy, cfg, pre_t, lds, st)) {
             fj = j;
             break;
         }
@@ -523,7 +532,7 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, SeqSetDev Rd, const 
         row->read = (int32_t)r; row->found = st.found; row->j = st.found ? fj : -1; row->dir = st.dir;
         row->ref_pos = st.ref_pos; row->cost = st.cost; row->matlen_a = st.ma; row->matlen_b = st.mb;
         row->n_trials = st.ntrials; row->n_pairs = st.npairs;
-        redo[r] = st.redo;
+        redo[r] = st.redo | (st.touch << 1);
     }
     }
 }
@@ -1518,11 +1527,15 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
 
 // One locked round over the reads `subset` (host ids; nullptr = every read).  rows is indexed by read id: rows of
 // reads outside the subset are left untouched.
+// Unlocked rounds (pba_cons_round) pass the grown text: ref_org = the index's position 0 inside it, maxn / maxm = the
+// size guard of the caller's t_aligner, touch[read id] = SsState::touch of the reads walked.
 static int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads,
                                double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel,
-                               const uint32_t *subset, uint32_t n_subset, pba_ss_row *rows) {
+                               const uint32_t *subset, uint32_t n_subset, pba_ss_row *rows, int ref_org = 0, int maxn = 0,
+                               int maxm = 0, uint8_t *touch = nullptr) {
     if (!ctx || !ix || !ref || !reads || !rows || ref_seq >= ref->n || max_trial < 0) return PBA_E_INVALID;
-    if (ix->mode != PBA_INDEX_HEAD_TAIL || ix->seq_len != ref->h_len[ref_seq])
+    if (ix->mode != PBA_INDEX_HEAD_TAIL || (!touch && ix->seq_len != ref->h_len[ref_seq]) || ref_org < 0 ||
+        (uint64_t)ref_org + ix->seq_len > ref->h_len[ref_seq])
         PBA_FAIL(PBA_E_INVALID, "pba_spaced_round needs a PBA_INDEX_HEAD_TAIL index of the reference sequence");
     if (reads->max_len > (uint32_t)kMaxSeqLen || ref->h_len[ref_seq] > 0x7FFFFFF0u)
         PBA_FAIL(PBA_E_TOOLONG, "sequence longer than the engine limit");
@@ -1531,7 +1544,7 @@ static int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs
     const uint32_t n = reads->n, n_first = subset ? n_subset : n;
     Plan pl;
     // a = reference window, b = read window: the shorter side bounds max_dst (seq_aligner.h:94-102)
-    int st = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
+    int st = make_plan(ctx, R, maxn, maxm, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (st != PBA_OK) return st;
     DevBuf d_rows, d_redo, d_ids, d_sub;
     HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_ss_row) * (n + 1)));
@@ -1545,7 +1558,7 @@ static int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs
     (void)hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream);                                                           \
     hipLaunchKernelGGL(k_spaced_round<NBV>, dim3(persistent_grid(ctx, cnt, Wpb<NBV>::v, pl.lds)),                     \
                        dim3(PBA_WAVE * Wpb<NBV>::v), pl.lds * Wpb<NBV>::v, ctx->stream, ix->dev(), ref->dev(),       \
-                       ref_seq, reads->dev(), ids, cnt, max_trial, overlap_min, buggy_seed_at, pl.cfg,               \
+                       ref_seq, ref_org, reads->dev(), ids, cnt, max_trial, overlap_min, buggy_seed_at, pl.cfg,      \
                        d_rows.as<pba_ss_row>(), d_redo.as<int>(), ctx->d_queue)
     if (n_first) {
         std::vector<int> h_redo(n);
@@ -1562,7 +1575,7 @@ static int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::vector<uint32_t> redo;
         for (uint32_t r = 0; r < n; ++r)
-            if (h_redo[r]) redo.push_back(r);
+            if (h_redo[r] & 1) redo.push_back(r);
         if (!redo.empty()) {
             HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * redo.size()));
             HIPCHK(hipMemcpyAsync(d_ids.p, redo.data(), sizeof(uint32_t) * redo.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -1576,7 +1589,9 @@ static int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipMemcpyAsync(h_rows.data(), d_rows.p, sizeof(pba_ss_row) * n, hipMemcpyDeviceToHost, ctx->stream));
+        if (touch && !redo.empty()) HIPCHK(hipMemcpyAsync(h_redo.data(), d_redo.p, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (touch) for (uint32_t r = 0; r < n; ++r) touch[r] = (uint8_t)((h_redo[r] >> 1) & 3);
         if (!subset) memcpy(rows, h_rows.data(), sizeof(pba_ss_row) * n);
         else for (uint32_t k = 0; k < n_subset; ++k) rows[subset[k]] = h_rows[subset[k]];
         prof_finish(ctx);
@@ -1895,6 +1910,7 @@ struct pba_cons {
     int cur;                              // which of the two array sets is live (evolve ping-pongs)
     ConsDev set[2];
     int *d_n;
+    int vote_ext;                         // votes of the running batch address the text of [pre, post) (pba_cons_round), not [beg, end)
 };
 
 static void cons_free_sets(pba_cons *c) {
@@ -2009,7 +2025,7 @@ int pba_cons_elect(pba_ctx *ctx, pba_cons *c, uint32_t n, const int32_t *pos, co
 
 static int cons_vote_view(const pba_cons *c, ConsDev *dev, int *beg, int *pre, int *post) {
     if (!c) return PBA_E_INVALID;
-    *dev = c->set[c->cur]; *beg = c->beg; *pre = c->pre; *post = c->post;
+    *dev = c->set[c->cur]; *beg = c->vote_ext ? c->pre : c->beg; *pre = c->pre; *post = c->post;
     return PBA_OK;
 }
 
@@ -2026,6 +2042,159 @@ int pba_cons_vote_pairs(pba_ctx *ctx, pba_cons *c, const pba_seqs *A, uint32_t r
             PBA_FAIL(PBA_E_INVALID, "pba_cons_vote_pairs: a must be the reference, both accessors in one direction");
     }
     return trace_batch(ctx, A, B, pairs, n, R, maxn, maxm, PBA_KERNEL_BITVEC, out, nullptr, nullptr, nullptr, c, overlap_min);
+}
+
+// the text of boxes [first, first+len) as a one-sequence set (packed on the device from the object's own text array)
+static int cons_text_seqs(pba_ctx *ctx, const pba_cons *c, int first, int len, pba_seqs **out) {
+    DevBuf d_offs;
+    const uint64_t offs[2] = {0, (uint64_t)len};
+    HIPCHK(hipMalloc(&d_offs.p, sizeof offs));
+    HIPCHK(hipMemcpyAsync(d_offs.p, offs, sizeof offs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return pba_seqs_from_device_text(ctx, c->set[c->cur].txt + first, d_offs.p, 1, (uint64_t)len, (uint32_t)len, out);
+}
+
+// One round of spaced_seed.cpp:420-446 against an UNLOCKED reference: the reads of `pool`, in order, each stopping at its
+// first success -- and every success votes (elect) and may grow the text (ref_seq.h:259-276), which the reads after it
+// then see.  Votes never change an alignment inside a round (the text changes in evolve), growth does, but only for a
+// candidate whose reference accessor is shorter than len_b + max_dst (seq_aligner.h:94-102): it `touches` an end.
+// So the round runs as a few batches: all pending reads are walked at once against the text as it stands
+// (k_spaced_round reports which ends each read's candidates touched); the rows are then taken in pool order, and a row
+// is the reference's as long as no earlier read of the batch has grown -- or been put back for -- an end it touches.
+// The accepted successes vote from their traceback walk (k_vote_pairs) against the batch's text, then the growths are
+// applied, and what was put back is the next batch.  The first pending read is always accepted, so it ends; a batch
+// takes at most one growth per end.
+int pba_cons_round(pba_ctx *ctx, pba_cons *c, const pba_seqs *reads, const uint32_t *pool, uint32_t n_pool, uint32_t mask,
+                   double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel, int maxn, int maxm,
+                   pba_ss_row *rows, pba_cons_round_stats *stats) {
+    if (!ctx || !c || !reads || (!pool && n_pool) || !rows || max_trial < 0) return PBA_E_INVALID;
+    for (uint32_t k = 0; k < n_pool; ++k)
+        if (pool[k] >= reads->n) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    pba_cons_round_stats S;
+    memset(&S, 0, sizeof S);
+    pba_seqs *base = nullptr;
+    pba_index *ix = nullptr;
+    int st = cons_text_seqs(ctx, c, c->beg, c->end - c->beg, &base);                 // get_seedmap reads [beg, end), ref_seq.h:291-311
+    if (st == PBA_OK) st = pba_index_build(ctx, base, 0, mask, PBA_INDEX_HEAD_TAIL, &ix);
+    if (st != PBA_OK) { pba_seqs_destroy(base); return st; }
+    S.n_index = (uint32_t)pba_index_entries(ix);
+    std::vector<uint32_t> pending(pool, pool + n_pool), deferred;
+    std::vector<uint8_t> touch(reads->n);
+    std::vector<char> rtext;
+    struct Growth { uint32_t read; bool fwd; int j, matlen_b; };
+    while (st == PBA_OK && !pending.empty()) {
+        ++S.n_batches;
+        pba_seqs *ext = base;
+        if (c->pre != c->beg || c->post != c->end) st = cons_text_seqs(ctx, c, c->pre, c->post - c->pre, &ext);
+        if (st != PBA_OK) break;
+        const int org = c->beg - c->pre, post_rel = c->post - c->beg, pre_rel = c->pre - c->beg;
+        st = spaced_round_subset(ctx, ix, ext, 0, reads, R, max_trial, overlap_min, buggy_seed_at, kernel, pending.data(),
+                                 (uint32_t)pending.size(), rows, org, maxn, maxm, touch.data());
+        std::vector<pba_pair> vp;
+        std::vector<uint32_t> vread;
+        std::vector<Growth> grow;
+        bool dirty_post = false, dirty_pre = false;
+        deferred.clear();
+        for (size_t k = 0; st == PBA_OK && k < pending.size(); ++k) {
+            const uint32_t r = pending[k];
+            if (((touch[r] & 1) && dirty_post) || ((touch[r] & 2) && dirty_pre)) {
+                deferred.push_back(r);               // what it does once it is re-walked is unknown: it may grow either end
+                dirty_post = dirty_pre = true;
+                continue;
+            }
+            const pba_ss_row &w = rows[r];
+            if (!w.found) continue;
+            const bool fwd = w.dir == 1;
+            const int slen = (int)reads->h_len[r], s_len = slen - w.j;                  // spaced_seed.cpp:274-275, both directions
+            const int r_off = fwd ? w.ref_pos : w.ref_pos + 15;                         // spaced_seed.cpp:285
+            const int la = fwd ? post_rel - r_off : r_off - pre_rel + 1;                // get_accessor, ref_seq.h:284-285
+            pba_pair pr;
+            memset(&pr, 0, sizeof pr);
+            pr.a_seq = 0; pr.a_pos = r_off + org; pr.a_len = la;
+            pr.b_seq = r; pr.b_pos = fwd ? w.j : slen - w.j - 1; pr.b_len = s_len;
+            pr.flags = fwd ? 0u : (PBA_A_BACKWARD | PBA_B_BACKWARD);
+            vp.push_back(pr); vread.push_back(r);
+            ++S.n_found;
+            if (w.matlen_a == la) {                                                     // ref_seq.h:268
+                grow.push_back(Growth{r, fwd, w.j, w.matlen_b});
+                if (fwd) dirty_post = true; else dirty_pre = true;
+            }
+        }
+        if (st == PBA_OK && !vp.empty()) {                                              // elect, ref_seq.h:267
+            std::vector<pba_result> out(vp.size());
+            c->vote_ext = 1;
+            st = trace_batch(ctx, ext, reads, vp.data(), vp.size(), R, maxn, maxm, PBA_KERNEL_BITVEC, out.data(), nullptr, nullptr,
+                             nullptr, c, overlap_min);
+            c->vote_ext = 0;
+            for (size_t q = 0; st == PBA_OK && q < vp.size(); ++q) {
+                const pba_ss_row &w = rows[vread[q]];
+                if (out[q].rc < 0 || out[q].cost != w.cost || out[q].matlen_a != w.matlen_a || out[q].matlen_b != w.matlen_b) {
+                    snprintf(ctx->err, sizeof ctx->err, "pba_cons_round: the voting walk of read %u disagrees with its round row", vread[q]);
+                    st = PBA_E_HIP;
+                }
+            }
+        }
+        for (size_t g = 0; st == PBA_OK && g < grow.size(); ++g) {                      // ref_seq.h:268-275
+            const Growth &G = grow[g];
+            const int slen = (int)reads->h_len[G.read], add = (slen - G.j) - G.matlen_b;
+            rtext.resize((size_t)slen + 1);
+            st = pba_seqs_get_text(ctx, reads, G.read, rtext.data(), rtext.size());
+            if (st != PBA_OK) break;
+            if (G.fwd) { st = pba_cons_append(ctx, c, rtext.data() + G.j + G.matlen_b, add); ++S.n_grown_fwd; }
+            else { st = pba_cons_prepend(ctx, c, rtext.data(), add); ++S.n_grown_bwd; }
+        }
+        if (ext != base) pba_seqs_destroy(ext);
+        S.n_deferred += (uint32_t)deferred.size();
+        pending.swap(deferred);
+    }
+    pba_index_destroy(ix);
+    pba_seqs_destroy(base);
+    if (stats) *stats = S;
+    return st;
+}
+
+// spaced_seed's main loop (spaced_seed.cpp:409-452) without -l: rounds of pba_cons_round over the reads not found yet,
+// seeds drawn as in pba_spaced_multi, evolve after every round that does not end the loop.
+int pba_cons_assemble(pba_ctx *ctx, pba_cons *c, const pba_seqs *reads, double R, int max_trial, int overlap_min,
+                      int buggy_seed_at, int kernel, int maxn, int maxm, const uint32_t *masks, int n_masks,
+                      const uint32_t *picks, int n_picks, int max_round, pba_ss_row *rows, int32_t *found_round,
+                      pba_ss_round_log *log, int32_t *ref_len_log, int log_cap, int *n_rounds) {
+    if (!ctx || !c || !reads || !masks || n_masks < 1 || !picks || n_picks < 1 || max_round < 0 || !rows || !found_round ||
+        !n_rounds || log_cap < 0 || ((!log || !ref_len_log) && log_cap))
+        return PBA_E_INVALID;
+    const uint32_t n = reads->n;
+    std::vector<uint32_t> pool(n);
+    for (uint32_t r = 0; r < n; ++r) { pool[r] = r; found_round[r] = 0; memset(&rows[r], 0, sizeof rows[r]); rows[r].read = (int32_t)r; rows[r].j = -1; }
+    int nfailure = 0, draws = 0, done = 0;
+    for (int nround = 1; nround <= max_round; ++nround) {
+        const uint32_t mask = nfailure == 0 ? masks[picks[draws++ % n_picks] % (uint32_t)n_masks] : masks[nfailure - 1];   // :412
+        pba_cons_round_stats S;
+        int st = pba_cons_round(ctx, c, reads, pool.data(), (uint32_t)pool.size(), mask, R, max_trial, overlap_min, buggy_seed_at,
+                                kernel, maxn, maxm, rows, &S);
+        if (st != PBA_OK) return st;
+        std::vector<uint32_t> rest;
+        rest.reserve(pool.size());
+        for (uint32_t r : pool) {
+            if (rows[r].found) found_round[r] = nround;                                     // erased from the pool, :443
+            else rest.push_back(r);
+        }
+        if (done < log_cap) { log[done].round = nround; log[done].mask = mask; log[done].n_tried = (int32_t)pool.size(); log[done].n_found = S.n_found; }
+        pool.swap(rest);
+        bool last = false;
+        if (S.n_found != 0) nfailure = 0;                                                   // :448-449
+        else if (++nfailure == n_masks) last = true;                                        // :450: break before evolve
+        if (!last) {
+            int32_t new_len = 0;
+            st = pba_cons_evolve(ctx, c, nullptr, 0, &new_len);                             // :451
+            if (st != PBA_OK) return st;
+            if (done < log_cap) ref_len_log[done] = new_len;
+        } else if (done < log_cap) ref_len_log[done] = c->post - c->pre;
+        ++done;
+        if (last) break;
+    }
+    *n_rounds = done;
+    return PBA_OK;
 }
 
 int pba_cons_evolve(pba_ctx *ctx, pba_cons *c, char *text_out, int cap, int32_t *new_len) {   // ref_seq.h:317-349

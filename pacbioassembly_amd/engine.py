@@ -438,6 +438,39 @@ class Consensus:
                                                         overlap_min, _ptr(out)), "cons_vote_pairs")
         return out[:pairs.size]
 
+    def round(self, reads: "SeqSet", pool, mask: int, R: float, max_trial: int = 32, overlap_min: int = 64,
+              buggy_seed_at: bool = False, kernel: int = PBA_KERNEL_AUTO, maxn: int = 26000, maxm: int = 6000):
+        """One unlocked round of spaced_seed.cpp:420-446 over the reads `pool` (ids, in order): pba_cons_round.
+        Returns (rows of the pool's reads in pool order, stats dict); the caller evolves."""
+        pool = np.ascontiguousarray(pool, np.uint32)
+        rows = np.zeros(max(reads.count, 1), SS_ROW_DTYPE)
+        st = np.zeros(6, np.int32)
+        self.ctx.check(self.ctx.lib.pba_cons_round(self.ctx.h, self.h, reads.h, _ptr(pool), pool.size, mask, R, max_trial,
+                                                   overlap_min, int(buggy_seed_at), kernel, maxn, maxm, _ptr(rows), _ptr(st)),
+                       "cons_round")
+        names = ("n_found", "n_batches", "n_grown_fwd", "n_grown_bwd", "n_deferred", "n_index")
+        return rows[pool], dict(zip(names, (int(x) for x in st)))
+
+    def assemble(self, reads: "SeqSet", R: float, masks, picks, max_round: int = 100, max_trial: int = 32,
+                 overlap_min: int = 64, buggy_seed_at: bool = False, kernel: int = PBA_KERNEL_AUTO, maxn: int = 26000,
+                 maxm: int = 6000):
+        """spaced_seed's main loop without -l (pba_cons_assemble); returns (rows, found_round, log list of dicts)."""
+        n = max(reads.count, 1)
+        rows = np.zeros(n, SS_ROW_DTYPE)
+        fr = np.zeros(n, np.int32)
+        log = np.zeros(max(max_round, 1), np.dtype([("round", "<i4"), ("mask", "<u4"), ("n_tried", "<i4"), ("n_found", "<i4")]))
+        rl = np.zeros(max(max_round, 1), np.int32)
+        masks = np.ascontiguousarray(masks, np.uint32); picks = np.ascontiguousarray(picks, np.uint32)
+        nr = C.c_int()
+        self.ctx.check(self.ctx.lib.pba_cons_assemble(self.ctx.h, self.h, reads.h, R, max_trial, overlap_min, int(buggy_seed_at),
+                                                      kernel, maxn, maxm, _ptr(masks), masks.size, _ptr(picks), picks.size,
+                                                      max_round, _ptr(rows), _ptr(fr), _ptr(log), _ptr(rl), log.size,
+                                                      C.byref(nr)), "cons_assemble")
+        out = [dict(zip(log.dtype.names, (int(x) for x in l))) for l in log[:nr.value]]
+        for k, d in enumerate(out):
+            d["ref_len"] = int(rl[k])
+        return rows[:reads.count], fr[:reads.count], out
+
     def evolve(self) -> bytes:
         cap = 3 * self.max_len
         buf = C.create_string_buffer(cap)

@@ -147,3 +147,67 @@ def locator_cli_inputs():
     texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(m["n_reads"])]
     texts = [t[:300 + 10 * (i % 13)] if i % 7 == 3 else t for i, t in enumerate(texts)]
     return g.tobytes(), texts
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# spaced_seed's main loop WITHOUT -l (spaced_seed.cpp:409-452): unlocked rounds -- every success votes and may grow the
+# reference, which the reads after it see -- and evolve after each round.  A short slice of a genome grows over its reads.
+ASSEMBLE = dict(genome_seed=61, genome_len=14000, slice=(5500, 3000), reads_seed=62, n_reads=220, read_len=1200,
+                err=(0.04, 0.04, 0.04), foreign_seed=63, n_foreign=20, weight=2, R=0.30, max_trial=32, overlap_min=64,
+                max_round=10, picks=[5, 2, 7, 7, 0, 3, 6, 1, 4, 2, 2, 5, 0, 7, 3, 1, 6, 4, 5, 5, 3, 0, 2, 6, 1, 7, 4])
+
+
+def assemble_inputs(cfg=None):
+    """Start reference, weight, the binary read file (reads of the genome in random order plus foreign ones), record
+    offsets, read texts."""
+    m = cfg or ASSEMBLE
+    g = eng.synth_genome(m["genome_seed"], m["genome_len"])
+    reads, offs, _ = eng.synth_reads(m["reads_seed"], g, m["n_reads"], m["read_len"], *m["err"])
+    f = eng.synth_genome(m["foreign_seed"], 20000)
+    fr, fo, _ = eng.synth_reads(m["foreign_seed"] + 1, f, m["n_foreign"], m["read_len"])
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(m["n_reads"])]
+    texts += [fr[int(fo[i]):int(fo[i + 1])].tobytes() for i in range(m["n_foreign"])]
+    order = np.random.RandomState(m["genome_seed"]).permutation(len(texts))
+    texts = [texts[i] for i in order]
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    p0, plen = m["slice"]
+    return g[p0:p0 + plen].tobytes(), m["weight"], file, rec_offs, texts
+
+
+def run_assembly(cons, masks, file, rec_offs, n_reads, cfg=None):
+    """spaced_seed.cpp:409-452 over any object with round(mask, R, max_trial, file, rec_offs, pool) -> (rows, nmatches),
+    evolve(), dump(), text().  Returns the record the goldens hold."""
+    m = cfg or ASSEMBLE
+    pool = list(range(n_reads))
+    rec = {"rounds": []}
+    nfailure, draws = 0, 0
+    for nround in range(1, m["max_round"] + 1):
+        if nfailure == 0:
+            mask = masks[m["picks"][draws % len(m["picks"])] % len(masks)]; draws += 1
+        else:
+            mask = masks[nfailure - 1]
+        rows, nm = cons.round(int(mask), m["R"], m["max_trial"], file, rec_offs, pool)
+        found = [[int(rows[c][k]) for c in ("read", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")]
+                 for k in range(len(pool)) if rows["found"][k]]
+        assert nm == len(found)
+        trials = hashlib.sha256(np.ascontiguousarray(rows["n_trials"]).tobytes() + np.ascontiguousarray(rows["n_pairs"]).tobytes()).hexdigest()[:16]
+        sel, sup, tot, ext = cons.dump()
+        r = {"round": nround, "mask": int(mask), "n_tried": len(pool), "found": found, "trials_pairs": trials, "extent": ext,
+             "votes": votes_digest(sel, sup, tot)}
+        pool = [p for k, p in enumerate(pool) if not rows["found"][k]]
+        last = False
+        if nm:
+            nfailure = 0
+        else:
+            nfailure += 1
+            last = nfailure == len(masks)
+        if not last:
+            cons.evolve()
+        t = cons.text()
+        r["ref_len"] = len(t); r["text_sha"] = hashlib.sha256(t).hexdigest()[:32]
+        rec["rounds"].append(r)
+        if last:
+            break
+    rec["final_text"] = cons.text().decode()
+    return rec

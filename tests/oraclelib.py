@@ -87,6 +87,8 @@ class Oracle:
         L.orc_cons_elect.argtypes = [_P, C.c_int, C.c_int, _P, _P, C.c_int]
         L.orc_cons_append.argtypes = [_P, _P, C.c_int]; L.orc_cons_prepend.argtypes = [_P, _P, C.c_int]
         L.orc_cons_evolve.argtypes = [_P]
+        L.orc_cons_round.restype = C.c_int
+        L.orc_cons_round.argtypes = [_P, _P, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]
         L.orc_cons_dump.restype = C.c_int; L.orc_cons_dump.argtypes = [_P, _P, _P, _P, C.c_int, _P]
         L.orc_cons_text.restype = C.c_int; L.orc_cons_text.argtypes = [_P, _P, C.c_int]
         self._aligner = None
@@ -253,6 +255,15 @@ class OracleCons(_ConsBase):
     def evolve(self):
         self.orc.lib.orc_cons_evolve(self.h)
 
+    def round(self, mask, R, max_trial, file: bytes, rec_offs, pool, buggy=True):
+        """one unlocked round of spaced_seed.cpp:420-446 over the records pool (in order); rows in pool order"""
+        buf = np.frombuffer(file + b"\0" * 65536, np.uint8)
+        offs = np.ascontiguousarray(rec_offs, np.uint64); pool = np.ascontiguousarray(pool, np.int32)
+        rows = np.zeros(max(pool.size, 1), ORC_SS_ROW)
+        nm = self.orc.lib.orc_cons_round(self.h, self.al, mask, R, max_trial, self.overlap_min, int(buggy), _ptr(buf), _ptr(offs),
+                                         _ptr(pool), pool.size, _ptr(rows))
+        return rows[:pool.size], nm
+
     def _dump(self, sel, sup, tot, cap, ext):
         return self.orc.lib.orc_cons_dump(self.h, _ptr(sel), _ptr(sup), _ptr(tot), cap, _ptr(ext))
 
@@ -278,6 +289,19 @@ class RefCons(_ConsBase):
 
     def evolve(self):
         self.lib.ref_cons_evolve()
+
+    def round(self, mask, R, max_trial, file: bytes, rec_offs, pool, buggy=True):
+        assert buggy, "the reference only has its own seed_at"
+        buf = np.frombuffer(file + b"\0" * 65536, np.uint8).copy()
+        offs = np.ascontiguousarray(rec_offs, np.uint64); pool = np.ascontiguousarray(pool, np.int32)
+        rows = np.zeros((max(pool.size, 1), 10), np.int32)
+        self.lib.ref_cons_round.restype = C.c_int
+        self.lib.ref_cons_round.argtypes = [C.c_uint32, C.c_double, C.c_int, _P, _P, _P, C.c_int, _P]
+        nm = self.lib.ref_cons_round(mask, R, max_trial, _ptr(buf), _ptr(offs), _ptr(pool), pool.size, _ptr(rows))
+        out = np.zeros(max(pool.size, 1), ORC_SS_ROW)
+        for k, name in enumerate(ORC_SS_ROW.names):
+            out[name] = rows[:, k]
+        return out[:pool.size], nm
 
     def _dump(self, sel, sup, tot, cap, ext):
         return self.lib.ref_cons_dump(_ptr(sel), _ptr(sup), _ptr(tot), cap, _ptr(ext))

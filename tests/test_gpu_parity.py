@@ -749,6 +749,97 @@ def test_spaced_multi_golden(ctx):
             assert [int(rows[c][r]) for c in ("found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")] == want, r
 
 
+class GpuAsm:
+    """The face run_assembly drives (round / evolve / dump / text) over pba_cons_round and the device vote boxes."""
+
+    def __init__(self, ctx, text, weight, reads, kernel=eng.PBA_KERNEL_AUTO):
+        self.c = eng.Consensus(ctx, text, weight, max_len=100000)
+        self.reads, self.kernel = reads, kernel
+        self.stats = []
+
+    def round(self, mask, R, max_trial, file, rec_offs, pool, buggy=True):
+        rows, st = self.c.round(self.reads, pool, mask, R, max_trial, 64, buggy_seed_at=buggy, kernel=self.kernel)
+        self.stats.append(st)
+        return rows, st["n_found"]
+
+    def evolve(self):
+        self.c.evolve()
+
+    def dump(self):
+        return self.c.dump()
+
+    def text(self):
+        return self.c.text()
+
+
+def test_assemble_unlocked_rounds_golden(ctx):
+    """pba_cons_round (an unlocked round of spaced_seed.cpp:420-446 as a few device batches: every pending read walked
+    at once, rows accepted in pool order until a growth they depend on, votes straight from the traceback walk) against
+    the reference's own serial loop on its ref_seq (tests/golden/assemble.json): per round the same reads found with the
+    same rows, the same probe and pair counts, the same extent and vote boxes before evolve, the same evolved text --
+    and the same 13 kb assembly grown from a 3 kb slice."""
+    from cons_scenarios import assemble_inputs, run_assembly
+    gold = gold_json("assemble.json")
+    text, weight, file, rec_offs, texts = assemble_inputs()
+    Rd = ctx.seqs_from_records(file, 0, 1 << 30)
+    assert Rd.count == len(texts)
+    for kernel in KERNELS:
+        asm = GpuAsm(ctx, text, weight, Rd, kernel)
+        got = run_assembly(asm, gold["masks"], file, rec_offs, len(texts))
+        for a, b in zip(got["rounds"], gold["rounds"]):
+            assert a == b, (kernel, a["round"], {k: (a[k], b[k]) for k in a if a[k] != b[k] and k != "found"})
+        assert got["final_text"] == gold["final_text"]
+        # the batching really happened: growth on both ends, reads put back behind it, far fewer launches than reads
+        assert sum(s["n_grown_fwd"] for s in asm.stats) >= 5 and sum(s["n_grown_bwd"] for s in asm.stats) >= 5
+        assert sum(s["n_deferred"] for s in asm.stats) > 0
+        assert sum(s["n_batches"] for s in asm.stats) < sum(len(r["found"]) for r in gold["rounds"])
+
+
+def test_assemble_whole_loop_golden(ctx):
+    """pba_cons_assemble (the whole of spaced_seed.cpp:409-452 without -l behind one call) == the golden chain: seeds,
+    pool sizes, matches and reference length per round, the round each read was found in, the final text."""
+    from cons_scenarios import ASSEMBLE, assemble_inputs
+    gold = gold_json("assemble.json")
+    text, weight, file, rec_offs, texts = assemble_inputs()
+    Rd = ctx.seqs_from_records(file, 0, 1 << 30)
+    c = eng.Consensus(ctx, text, weight, max_len=100000)
+    rows, fr, log = c.assemble(Rd, ASSEMBLE["R"], gold["masks"], ASSEMBLE["picks"], ASSEMBLE["max_round"], ASSEMBLE["max_trial"],
+                               ASSEMBLE["overlap_min"], buggy_seed_at=True)
+    assert [[l["round"], l["mask"], l["n_tried"], l["n_found"], l["ref_len"]] for l in log] == \
+        [[r["round"], r["mask"], r["n_tried"], len(r["found"]), r["ref_len"]] for r in gold["rounds"]]
+    want_round = {f[0]: r["round"] for r in gold["rounds"] for f in r["found"]}
+    assert fr.tolist() == [want_round.get(i, 0) for i in range(len(texts))]
+    for r in gold["rounds"]:
+        for f in r["found"]:
+            assert [int(rows[c_][f[0]]) for c_ in ("read", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b")] == f
+    assert c.text().decode() == gold["final_text"]
+
+
+def test_assemble_fresh_inputs_vs_oracle(ctx, oracle):
+    """Unlocked rounds on inputs no golden holds (other seeds, an insertion-heavy error mix, the intended seed_at as well
+    as the reference's): GPU == oracle, round by round."""
+    from cons_scenarios import ASSEMBLE, assemble_inputs, run_assembly
+    masks = [oracle.mask_from_pattern(p) for p in ("111*11*11*1*1111", "1111*1*11**11*111", "11*1111**1*11*111")]
+    cfg = dict(ASSEMBLE, genome_seed=81, reads_seed=82, foreign_seed=83, err=(0.02, 0.08, 0.03), slice=(3000, 2500), max_round=6)
+    text, weight, file, rec_offs, texts = assemble_inputs(cfg)
+    Rd = ctx.seqs_from_records(file, 0, 1 << 30)
+    for buggy in (True, False):
+        class O:                                   # the oracle with this seed_at
+            def __init__(s): s.c = oracle.consensus(text, weight)
+            def round(s, mask, R, mt, f, ro, pool): return s.c.round(mask, R, mt, f, ro, pool, buggy=buggy)
+            def evolve(s): s.c.evolve()
+            def dump(s): return s.c.dump()
+            def text(s): return s.c.text()
+        want = run_assembly(O(), masks, file, rec_offs, len(texts), cfg)
+        asm = GpuAsm(ctx, text, weight, Rd)
+        asm_round = asm.round
+        asm.round = lambda mask, R, mt, f, ro, pool: asm_round(mask, R, mt, f, ro, pool, buggy=buggy)
+        got = run_assembly(asm, masks, file, rec_offs, len(texts), cfg)
+        for a, b in zip(got["rounds"], want["rounds"]):
+            assert a == b, (buggy, a["round"], {k: (a[k], b[k]) for k in a if a[k] != b[k] and k != "found"})
+        assert got["final_text"] == want["final_text"] and sum(len(r["found"]) for r in want["rounds"]) > 40
+
+
 def test_edge_cases_of_the_widened_entry_points(ctx, oracle):
     """Empty / degenerate inputs of the traceback, consensus, multi-round and overlap entry points: defined answers or
     status codes, never a crash."""

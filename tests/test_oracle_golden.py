@@ -184,6 +184,23 @@ def test_spaced_multi_golden(oracle):
     assert sum(1 for x in found_round if x) > 100 and len({x for x in found_round}) >= 5
 
 
+def test_assemble_golden(oracle):
+    """spaced_seed's main loop WITHOUT -l (unlocked rounds: votes and growth inside a round, evolve after it, seed
+    rotation, pool erasure) recorded from the reference's own ref_seq (tests/golden/assemble.json): the oracle's
+    orc_cons_round / evolve chain reproduces every round -- reads found and their rows, probe and pair counts, extent,
+    vote boxes, evolved text -- and the final assembly."""
+    from cons_scenarios import assemble_inputs, run_assembly
+    gold = gold_json("assemble.json")
+    text, weight, file, rec_offs, texts = assemble_inputs()
+    got = run_assembly(oracle.consensus(text, weight), gold["masks"], file, rec_offs, len(texts))
+    assert len(got["rounds"]) == len(gold["rounds"])
+    for a, b in zip(got["rounds"], gold["rounds"]):
+        assert a == b, a["round"]
+    assert got["final_text"] == gold["final_text"]
+    assert len(gold["final_text"]) > 4 * len(text) and sum(len(r["found"]) for r in gold["rounds"]) > 150
+    assert any(r["extent"][0] < 0 for r in gold["rounds"]) and any(r["extent"][1] > r["extent"][2] for r in gold["rounds"])
+
+
 def test_locator_cli_golden(oracle):
     """The stdout of the reference's own `locator` main, unmodified (tests/golden/locator_cli.json: contig file, pattern,
     reads on stdin, R = 0.15, its seq_aligner<40000,6000>): the oracle's locator driver prints the same rows."""

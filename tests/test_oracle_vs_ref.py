@@ -90,3 +90,19 @@ def test_consensus_fresh_inputs(oracle, ref):
         b = run_scenario(ref.consensus(text, weight), reads)
         assert a == b, sc[0]
         assert sum(t[4] for r in b["rounds"] for t in r["tries"]) >= 8
+
+
+def test_assembly_fresh_inputs(oracle, ref):
+    """Unlocked multi-round assembly (spaced_seed.cpp:409-452 without -l) on seeds and error mixes the golden does not
+    hold: oracle == the reference's ref_seq, round by round."""
+    from cons_scenarios import ASSEMBLE, assemble_inputs, run_assembly
+    masks = [oracle.mask_from_pattern(p) for p in ("111*11*11*1*1111", "1111*1*11**11*111", "11*1111**1*11*111")]
+    for k, over in enumerate([dict(genome_seed=71, reads_seed=72, foreign_seed=73, err=(0.02, 0.08, 0.03), slice=(3000, 2500), max_round=6),
+                              dict(genome_seed=74, reads_seed=75, foreign_seed=76, err=(0.05, 0.05, 0.05), slice=(9000, 4000), weight=1,
+                                   n_reads=150, read_len=1500, max_round=5)]):
+        cfg = dict(ASSEMBLE, **over)
+        text, weight, file, rec_offs, texts = assemble_inputs(cfg)
+        a = run_assembly(oracle.consensus(text, weight), masks, file, rec_offs, len(texts), cfg)
+        b = run_assembly(ref.consensus(text, weight), masks, file, rec_offs, len(texts), cfg)
+        assert a == b, k
+        assert sum(len(r["found"]) for r in b["rounds"]) > 40 and len(b["final_text"]) > len(text) + 1000
