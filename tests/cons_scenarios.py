@@ -211,3 +211,34 @@ def run_assembly(cons, masks, file, rec_offs, n_reads, cfg=None):
             break
     rec["final_text"] = cons.text().decode()
     return rec
+
+
+# the reference's own spaced_seed main on the ASSEMBLE reads (tests/golden/make_golden.py: gen_spaced_seed_cli)
+SPACED_SEED_CLI = dict(pattern="111*11*11*1*1111", runs={"unlocked": ["-m", "5", "-t", "32"], "locked": ["-l", "-m", "3", "-t", "32"],
+                                                         "unlocked_r20": ["-m", "3", "-t", "20", "-r", "0.2"]})
+
+
+def run_spaced_seed_cli(exe, workdir, extra):
+    """Run a spaced_seed-compatible program on the ASSEMBLE inputs (reference text in a file WITHOUT a trailing newline:
+    fgets then stops at EOF and the weight stays 1; a one-line seed file: rand() % 1) and return what the goldens hold."""
+    import hashlib
+    import re
+    import subprocess
+    import os
+    text, weight, file, rec_offs, texts = assemble_inputs()
+    open(os.path.join(workdir, "seqs.bin"), "wb").write(file)
+    open(os.path.join(workdir, "ref.txt"), "wb").write(text)
+    open(os.path.join(workdir, "seed.txt"), "w").write(SPACED_SEED_CLI["pattern"] + "\n")
+    out = {}
+    for name, flags in SPACED_SEED_CLI["runs"].items():
+        dump = os.path.join(workdir, name + ".dump")
+        r = subprocess.run([exe, "-f", "ref.txt", "-d", dump] + flags + extra + ["seqs.bin", "seed.txt"], cwd=workdir, capture_output=True,
+                           check=True, timeout=600)
+        lines = r.stdout.split(b"\n")
+        assert lines[-1] == b""
+        found = [[int(x) for x in m] for m in re.findall(r"found (\d+) at cost (\d+):\tref_ml=(\d+),\tseg_ml=(\d+)", r.stderr.decode())]
+        out[name] = {"consensus_len": [len(l) for l in lines[:-1]],
+                     "consensus_sha": [hashlib.sha256(l).hexdigest()[:32] for l in lines[:-1]],
+                     "last_consensus": lines[-2].decode(), "found": found,
+                     "dump_sha": hashlib.sha256(open(dump, "rb").read()).hexdigest()[:32], "dump_lines": open(dump, "rb").read().count(b"\n")}
+    return out

@@ -987,6 +987,28 @@ def test_locator_gpu_example_prints_what_the_reference_locator_prints(lib, tmp_p
     assert rows == gold["rows"] and len(rows) > 250
 
 
+def test_spaced_seed_gpu_example_prints_what_the_reference_spaced_seed_prints(lib, tmp_path):
+    """examples/spaced_seed_gpu.cpp (the reference's `spaced_seed` command line over the C ABI, plain g++) against the
+    reference's own main, compiled unmodified and run on the same files (tests/golden/spaced_seed_cli.json): the same
+    consensus on stdout after every round, the same `found` lines in the log, the same -d dump file -- unlocked (the
+    assembly: votes, growth, evolve), unlocked at another ratio / trial count, and locked."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from cons_scenarios import run_spaced_seed_cli
+    gold = gold_json("spaced_seed_cli.json")["runs"]
+    out = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "spaced_seed_gpu")
+    libdir = os.path.join(ROOT, "pacbioassembly_amd", "lib")
+    subprocess.run(["g++", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "examples", "spaced_seed_gpu.cpp"), "-L", libdir, "-lpba", f"-Wl,-rpath,{libdir}"], check=True)
+    got = run_spaced_seed_cli(exe, str(tmp_path), [])
+    for name in gold:
+        assert got[name] == gold[name], (name, {k: (got[name][k], gold[name][k]) for k in gold[name] if got[name][k] != gold[name][k] and k != "last_consensus"})
+
+
 def test_locate_random_configs_vs_oracle():
     """tools/stress_locate.py: random genome sizes, ragged read lengths, error mixes up to the acceptance limit, R from 0.1
     to 0.45, 10 or 50 probe offsets, both kernels -- rows and counted pairs / cells equal the oracle's."""

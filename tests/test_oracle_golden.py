@@ -201,6 +201,27 @@ def test_assemble_golden(oracle):
     assert any(r["extent"][0] < 0 for r in gold["rounds"]) and any(r["extent"][1] > r["extent"][2] for r in gold["rounds"])
 
 
+def test_spaced_seed_cli_golden(oracle):
+    """The reference's own `spaced_seed` main, unmodified (tests/golden/spaced_seed_cli.json: -f ref_file, a one-line
+    seed file, its t_aligner and OVERLAP_MIN, no -l): the consensus it prints after every round and the `found` lines
+    of its log are what the oracle's unlocked rounds produce."""
+    import hashlib
+    from cons_scenarios import ASSEMBLE, SPACED_SEED_CLI, assemble_inputs, run_assembly
+    gold = gold_json("spaced_seed_cli.json")["runs"]
+    text, _, file, rec_offs, texts = assemble_inputs()
+    mask = oracle.mask_from_pattern(SPACED_SEED_CLI["pattern"])
+    for name, R, mt, mr in (("unlocked", 0.3, 32, 5), ("unlocked_r20", 0.2, 20, 3)):
+        cfg = dict(ASSEMBLE, R=R, max_trial=mt, max_round=mr)
+        rec = run_assembly(oracle.consensus(text, 1), [mask], file, rec_offs, len(texts), cfg)
+        g = gold[name]
+        printed = [r for r in rec["rounds"] if r["found"]]                    # a round without a match ends the loop unprinted
+        assert [r["ref_len"] for r in printed] == g["consensus_len"], name
+        assert [r["text_sha"] for r in printed] == g["consensus_sha"], name
+        assert [[f[0], f[4], f[5], f[6]] for r in rec["rounds"] for f in r["found"]] == g["found"], name
+        assert hashlib.sha256(g["last_consensus"].encode()).hexdigest()[:32] == g["consensus_sha"][-1]
+    assert len(gold["unlocked"]["found"]) > 100 and gold["unlocked"]["consensus_len"][-1] > 3 * len(text)
+
+
 def test_locator_cli_golden(oracle):
     """The stdout of the reference's own `locator` main, unmodified (tests/golden/locator_cli.json: contig file, pattern,
     reads on stdin, R = 0.15, its seq_aligner<40000,6000>): the oracle's locator driver prints the same rows."""
