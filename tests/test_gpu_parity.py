@@ -1009,6 +1009,26 @@ def test_spaced_seed_gpu_example_prints_what_the_reference_spaced_seed_prints(li
         assert got[name] == gold[name], (name, {k: (got[name][k], gold[name][k]) for k in gold[name] if got[name][k] != gold[name][k] and k != "last_consensus"})
 
 
+def test_assemble_tool_other_configs_vs_oracle():
+    """tools/bench_assemble.py with the oracle beside every round (rows, probe / pair counts, vote boxes, evolved text):
+    other genome sizes, read lengths, error rates and trial counts than the goldens hold; a random read order."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for args in (["--genome", "40000", "--reads", "250", "--read-len", "2500", "--err", "0.12", "--start-len", "6000", "--rounds", "6",
+                  "--check-rounds", "6", "--seed", "11"],
+                 ["--genome", "30000", "--reads", "200", "--read-len", "1800", "--err", "0.18", "--start-len", "4000", "--rounds", "5",
+                  "--check-rounds", "5", "--trials", "20", "--seed", "12"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_assemble.py")] + args, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        assert recs[-1]["checked_same"] and all(x["same_as_oracle"] for x in recs[:-1]), r.stdout
+        assert recs[-1]["found"] >= 10 and sum(x["batches"] for x in recs[:-1]) > len(recs) - 1
+
+
 def test_locate_random_configs_vs_oracle():
     """tools/stress_locate.py: random genome sizes, ragged read lengths, error mixes up to the acceptance limit, R from 0.1
     to 0.45, 10 or 50 probe offsets, both kernels -- rows and counted pairs / cells equal the oracle's."""
