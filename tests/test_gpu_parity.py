@@ -889,6 +889,22 @@ def test_edge_cases_of_the_widened_entry_points(ctx, oracle):
     one = ctx.seqs_from_list([b"ACGT" * 300])
     ov, st = ctx.overlap_all(one, 0xFFCCF3FC, 0.3, 8, 64)
     assert ov.size == 0 and st["n_overlaps"] == 0
+    # unlocked rounds: an empty pool, a reference shorter than a seed, an empty reference, a read that IS the reference
+    rd = eng.synth_genome(5, 900).tobytes()
+    Rd = ctx.seqs_from_records(eng.text2bin(rd) + eng.text2bin(rd[100:800]), 0, 1 << 30)
+    c4 = eng.Consensus(ctx, rd, 1, max_len=5000)
+    rows, st = c4.round(Rd, [], 0xFFCCF3FC, 0.3)
+    assert rows.size == 0 and st["n_found"] == 0 and st["n_batches"] == 0
+    for tiny in (b"ACGTACGTAC", b""):
+        rows, st = eng.Consensus(ctx, tiny, 1, max_len=5000).round(Rd, [0, 1], 0xFFCCF3FC, 0.3)
+        assert not rows["found"].any() and st["n_index"] == 0
+    rows, st = c4.round(Rd, [1, 0], 0xFFCCF3FC, 0.3)                   # exact copies: found at j = 0, cost 0, nothing grows
+    assert rows["found"].tolist() == [1, 1] and rows["cost"].tolist() == [0, 0] and rows["ref_pos"].tolist() == [100, 0]
+    assert st["n_grown_fwd"] + st["n_grown_bwd"] <= 1 and c4.extent() == [0, 900, 900]
+    sel, sup, tot, _ = c4.dump()
+    assert tot[:100].tolist() == [2] * 100 and tot[100:800].tolist() == [3] * 700 and c4.evolve() == rd
+    rows, fr, log = eng.Consensus(ctx, rd, 1, max_len=5000).assemble(empty, 0.3, [0xFFCCF3FC], [0], 5)
+    assert rows.size == 0 and len(log) == 1
 
 
 def test_cons_vote_pairs_equals_scripts_then_elect(ctx):
