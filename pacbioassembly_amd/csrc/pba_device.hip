@@ -1838,43 +1838,60 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     };
     // narrow window for items [lo, hi), then the runs it parked at the reference band; returns the number parked
     uint64_t parked_total = 0;
-    auto narrow_then_redo = [&](size_t lo, size_t hi, uint64_t *parked) -> int {
+    // items [lo, hi) in the ring nb_first with its first-pass window, then what that parked in the widest ring below the
+    // reference band's (its window takes all the room the ring has, bv_pass1_w: at 15 kb NB = 3 holds 4 072 of max_dst
+    // 4 501), then what is still parked at the reference band; returns the number parked by the first stage
+    int nb_mid = 0;
+    for (int nb : {1, 2, 3, 4, 6})
+        if (nb > pl.nb1 && nb < pl.nb2) nb_mid = nb;
+    auto narrow_then_redo = [&](int nb_first, size_t lo, size_t hi, uint64_t *parked) -> int {
         *parked = 0;
         if (hi <= lo) return PBA_OK;
-        int rc2 = walk(pl.nb1, d_items.as<uint2>() + lo, (uint32_t)(hi - lo), 0, nullptr);
+        int rc2 = walk(nb_first, d_items.as<uint2>() + lo, (uint32_t)(hi - lo), 0, nullptr);
         if (rc2 != PBA_OK) return rc2;
-        unsigned long long h_redo = 0;
-        HIPCHK(hipMemcpyAsync(&h_redo, d_cnt64.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (h_redo > redo_cap) PBA_FAIL(PBA_E_NOMEM, "pba_overlap_all: more uncertified (target, query) runs than the redo list holds");
-        *parked = h_redo;
-        if (!h_redo) return PBA_OK;
-        DevBuf d_in;
-        HIPCHK(hipMalloc(&d_in.p, sizeof(uint2) * h_redo));
-        HIPCHK(hipMemcpyAsync(d_in.p, d_redo.p, sizeof(uint2) * h_redo, hipMemcpyDeviceToDevice, ctx->stream));
-        rc2 = walk(pl.nb2, nullptr, (uint32_t)h_redo, 1, d_in.as<uint2>());
-        if (rc2 != PBA_OK) return rc2;
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int stage = 0; stage < 2; ++stage) {
+            unsigned long long h_redo = 0;
+            HIPCHK(hipMemcpyAsync(&h_redo, d_cnt64.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (h_redo > redo_cap) PBA_FAIL(PBA_E_NOMEM, "pba_overlap_all: more uncertified (target, query) runs than the redo list holds");
+            if (stage == 0) *parked = h_redo;
+            if (!h_redo) return PBA_OK;
+            if (stage == 0 && nb_mid <= nb_first) continue;      // no ring between this one and the reference band's
+            DevBuf d_in;
+            HIPCHK(hipMalloc(&d_in.p, sizeof(uint2) * h_redo));
+            HIPCHK(hipMemcpyAsync(d_in.p, d_redo.p, sizeof(uint2) * h_redo, hipMemcpyDeviceToDevice, ctx->stream));
+            rc2 = stage == 0 ? walk(nb_mid, nullptr, (uint32_t)h_redo, 0, d_in.as<uint2>())
+                             : walk(pl.nb2, nullptr, (uint32_t)h_redo, 1, d_in.as<uint2>());
+            if (rc2 != PBA_OK) return rc2;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
         return PBA_OK;
     };
     // Whether the narrow window pays depends on how far the reads are from each other (two 15 % reads differ by ~27 %:
     // nothing certifies below the reference band), which only the data tells: a sample of the items goes through
-    // narrow-then-redo, and if most of its successful runs had to be parked the rest goes straight to the reference band.
+    // narrow-then-redo, and if most of its successful runs had to be parked the rest starts wider: in the widest ring
+    // below the reference band's (its first-pass window takes all the room that ring has, bv_pass1_w -- at 15 kb NB = 3
+    // holds a window of 4 072, which certifies every overlap but the longest), or straight at the reference band.
     const size_t n_all = h_items.size();
-    const size_t n_sample = pl.nb1 == 0 ? n_all : std::min(n_all, std::max<size_t>(4096, n_all / 32));
+    size_t sample_min = 4096;
+    if (const char *e = getenv("PBA_OVL_SAMPLE_MIN")) sample_min = (size_t)std::max(1L, atol(e));   // test hook: small inputs through the sampled decision
+    const size_t n_sample = pl.nb1 == 0 ? n_all : std::min(n_all, std::max<size_t>(sample_min, n_all / 32));
     uint64_t parked = 0;
-    rc = narrow_then_redo(0, n_sample, &parked);
+    rc = narrow_then_redo(pl.nb1, 0, n_sample, &parked);
     if (rc != PBA_OK) return rc;
     parked_total += parked;
     if (n_sample < n_all) {
         unsigned long long h_ov = 0;
         HIPCHK(hipMemcpyAsync(&h_ov, d_cnt64.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (2 * parked > h_ov) {                                 // most overlaps of the sample needed the reference band
-            rc = walk(pl.nb2, d_items.as<uint2>() + n_sample, (uint32_t)(n_all - n_sample), 1, nullptr);
+        if (2 * parked > h_ov) {                                 // most overlaps of the sample needed more than the narrow window
             st.wide_first = 1;
+            if (nb_mid) {
+                rc = narrow_then_redo(nb_mid, n_sample, n_all, &parked);
+                parked_total += parked;
+            } else rc = walk(pl.nb2, d_items.as<uint2>() + n_sample, (uint32_t)(n_all - n_sample), 1, nullptr);
         } else {
-            rc = narrow_then_redo(n_sample, n_all, &parked);
+            rc = narrow_then_redo(pl.nb1, n_sample, n_all, &parked);
             parked_total += parked;
         }
         if (rc != PBA_OK) return rc;

@@ -645,6 +645,35 @@ def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):
     assert st["n_pairs"] == pairs
 
 
+def test_overlap_all_cascade_through_the_middle_ring(ctx, oracle, monkeypatch):
+    """14 kb reads at 15 % error each (~27 % between two of them): max_dst = 4 201 puts the narrow window in a two-block
+    ring (window 2 729) and the reference band in a four-block one, so the runs the first stage parks are resumed in
+    the three-block ring (window 4 072: all the room it has) and only what that cannot certify goes on to the reference
+    band -- same overlaps and pair counts as the row-sweep kernel (which has no windows at all), with and without the
+    sampled decision, and as the oracle's composition for the first targets."""
+    g = eng.synth_genome(301, 60000)
+    n, rl = 36, 14000
+    reads, offs, _ = eng.synth_reads(302, g, n, rl, 0.05, 0.05, 0.05)
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+    mask = eng.mask_from_pattern(MASK_PAT)
+    S = ctx.seqs_from_list(texts, strict_acgt=True)
+    want, st_rs = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_ROWSWEEP)
+    assert len(want) > 30
+    for sample in (None, "2"):
+        if sample:
+            monkeypatch.setenv("PBA_OVL_SAMPLE_MIN", sample)         # the rest of the items goes through the sampled decision
+        got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_BITVEC)
+        assert [tuple(int(x) for x in r) for r in got] == [tuple(int(x) for x in r) for r in want], sample
+        assert st["n_pairs"] == st_rs["n_pairs"] and st["n_redo"] > 3
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    for t in range(3):
+        rows = oracle.spaced_round(texts[t], mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=16)
+        exp = [(t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]), int(rows["matlen_a"][q]),
+                int(rows["matlen_b"][q])) for q in range(n) if q != t and rows["found"][q]]
+        assert [tuple(int(x) for x in r) for r in got if int(r["target"]) == t] == exp, t
+
+
 # ----------------------------------------------------------------------------- consensus (ref_seq, unlocked)
 class GpuCons:
     """ref_seq::try_align (ref_seq.h:259-276) composed from the C ABI: align + edit script on the GPU, votes and
