@@ -82,14 +82,15 @@ __device__ __forceinline__ uint32_t compress_even64(uint64_t x) {
 }
 
 // bit planes of 32 consecutive accessor elements starting at element e: bit r of plo/phi = low/high bit of
-// element e+r.  From the set's precomputed planes: two dword loads and one funnel shift per plane (the index may run
-// a few hundred bases before / past the sequence: neighbours or zero slack, never used).
+// element e+r.  From the set's precomputed planes, stored word by word side by side (low word w, high word w, low word
+// w+1, ...): four consecutive dwords -- one 16-byte fetch, one cache line for both planes -- and one funnel shift per
+// plane (the index may run a few hundred bases before / past the sequence: neighbours or zero slack, never used).
 __device__ __forceinline__ void load_planes32(const PackedFetch &f, int e, uint32_t &plo, uint32_t &phi) {
     const int idx = f.dir > 0 ? f.org + e : f.org - e - 31;          // lowest base index of the 32, in memory order
-    const uint32_t *p = f.pl + (idx >> 5);                            // (arithmetic shift: negative indices reach the slack)
+    const uint32_t *p = f.pl + 2 * (ptrdiff_t)(idx >> 5);             // (arithmetic shift: negative indices reach the slack)
     const uint32_t sh = (uint32_t)idx & 31u;
-    const uint32_t lo = __builtin_amdgcn_alignbit(p[1], p[0], sh);    // ({p[1], p[0]} >> sh)[31:0]
-    const uint32_t hi = __builtin_amdgcn_alignbit(p[f.hi + 1], p[f.hi], sh);
+    const uint32_t lo = __builtin_amdgcn_alignbit(p[2], p[0], sh);    // ({low[w+1], low[w]} >> sh)[31:0]
+    const uint32_t hi = __builtin_amdgcn_alignbit(p[3], p[1], sh);
     plo = f.dir > 0 ? lo : __builtin_bitreverse32(lo);                // backward: element r is base idx + 31 - r
     phi = f.dir > 0 ? hi : __builtin_bitreverse32(hi);
 }

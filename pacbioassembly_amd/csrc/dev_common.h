@@ -17,9 +17,9 @@ struct SeqSetDev {
     // The same bases as two bit planes (bit p of sequence i's stream = low / high bit of its base p, LSB first, every
     // sequence starting on a word): what the bit-vector kernels consume.  Built once per set (k_make_planes) so that
     // 32 bases of either plane are two dword loads and a funnel shift instead of a 60-instruction bit de-interleave.
-    const uint32_t *plane;   // low plane; >= 32 zero words before the first and after the last sequence
-    const uint64_t *poff;    // word offset of sequence i in a plane
-    uint64_t hi_words;       // words from the low plane to the high plane
+    // The planes are stored side by side: plane[2w] = low word w, plane[2w+1] = high word w (one cache line for both).
+    const uint32_t *plane;   // word pair 0; >= 32 zero pairs before the first and after the last sequence
+    const uint64_t *poff;    // word (pair) offset of sequence i
 };
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
@@ -49,20 +49,19 @@ struct PackedFetch {
     const uint8_t *seq;   // first packed byte of the sequence
     int org;              // accessor origin (base index)
     int dir;              // +1 forward, -1 backward
-    const uint32_t *pl;   // the sequence's first word in the low bit plane
-    uint64_t hi;          // words from the low plane to the high plane
+    const uint32_t *pl;   // the sequence's first pair of plane words (low word, high word, low word of the next 32 bases, ...)
     __device__ __forceinline__ int operator()(int k) const {
         const int idx = org + dir * k;
         return (seq[idx >> 2] >> (6 - 2 * (idx & 3))) & 3;
     }
     // the same sequence from another origin / in another direction
     __device__ __forceinline__ PackedFetch at(int origin, int direction) const {
-        return PackedFetch{seq, origin, direction, pl, hi};
+        return PackedFetch{seq, origin, direction, pl};
     }
 };
 // accessor on sequence `id` of a set (dna_seq.h:191: origin + direction)
 __device__ __forceinline__ PackedFetch fetch_of(const SeqSetDev &S, uint32_t id, int org, int dir) {
-    return PackedFetch{S.packed + S.off[id], org, dir, S.plane + S.poff[id], S.hi_words};
+    return PackedFetch{S.packed + S.off[id], org, dir, S.plane + 2 * S.poff[id]};
 }
 struct ByteFetch {
     const uint8_t *org;   // accessor origin (pointer to element 0)

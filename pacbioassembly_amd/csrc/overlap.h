@@ -137,13 +137,11 @@ struct OvlCand {
     uint32_t q;
     int j, hit, r_off, r_len, s_off, s_len;
 };
-__device__ __forceinline__ OvlCand ovl_decode(const SeqSetDev &Rd, int ref_len, const HeadTail &ht, uint64_t cd,
-                                              const OvlCfg &cfg) {
+__device__ __forceinline__ OvlCand ovl_decode_len(int slen, int ref_len, const HeadTail &ht, uint64_t cd, const OvlCfg &cfg) {
     OvlCand c;
     c.q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
     const uint32_t jd = (uint32_t)(cd >> PBA_OVL_ORD_BITS) & ((1u << PBA_OVL_JD_BITS) - 1);
     c.hit = ht.pos_of((int)(cd & ((1u << PBA_OVL_ORD_BITS) - 1)));
-    const int slen = (int)Rd.len[c.q];
     c.j = (int)(jd >> 1);
     c.fwd = (jd & 1) == 0;
     const int pos = c.fwd ? c.j : slen - c.j - 16;
@@ -153,6 +151,10 @@ __device__ __forceinline__ OvlCand ovl_decode(const SeqSetDev &Rd, int ref_len, 
     c.r_off = c.fwd ? c.hit : c.hit + 15;                       // spaced_seed.cpp:285
     c.r_len = c.fwd ? ref_len - c.r_off : c.r_off + 1;          // ref_seq.h:284-285
     return c;
+}
+__device__ __forceinline__ OvlCand ovl_decode(const SeqSetDev &Rd, int ref_len, const HeadTail &ht, uint64_t cd,
+                                              const OvlCfg &cfg) {
+    return ovl_decode_len((int)Rd.len[(uint32_t)(cd >> PBA_OVL_Q_SHIFT)], ref_len, ht, cd, cfg);
 }
 
 __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long cap, unsigned long long *n_out, uint32_t t,
@@ -188,10 +190,17 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
     uint16_t *lds = (uint16_t *)(lds_all + (size_t)wave * cfg.row_cap * 2);
     const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
     const PreThresholds pre_t(cfg.R);
+    // A million reads make hundreds of millions of light items (a group of 64 mostly false candidates): one atomic on
+    // the queue and one on the pair counter per item is then what the walk waits for (every wavefront on the same two
+    // addresses).  Items are taken 16 at a time there and the pairs are added up per wavefront.
+    const uint32_t chunk = (redo_in || n_items < (1u << 20)) ? 1u : 16u;
+    unsigned long long pairs = 0;
     for (;;) {
-        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)atomicAdd(queue, l0 ? 1u : 0u));                       // see next_slot() in pba_device.hip
-        if (item >= n_items) break;
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)atomicAdd(queue, l0 ? chunk : 0u));                    // see next_slot() in pba_device.hip
+        if (base >= n_items) break;
+        const uint32_t item_end = min(n_items, base + chunk);
+        for (uint32_t item = base; item < item_end; ++item) {
         const uint32_t NONE = 0xFFFFFFFFu;
         uint32_t tl, c_begin, c_end, own_end, skip_q = NONE, only_q = NONE;
         if (redo_in) {
@@ -207,7 +216,6 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
         const int ref_len = (int)Rd.len[t];
         const HeadTail ht(ref_len);
         uint32_t done_q = NONE, last_q = NONE;
-        unsigned long long pairs = 0;
         bool stop = false;
         // 64 candidates at a time: every lane decodes its candidate and runs its first 32 rows (prefilter.h); then the
         // group is walked in order and only the candidates that survived get the wavefront
@@ -219,32 +227,51 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), ng = min((uint32_t)PBA_WAVE, c_end - c0);
             const bool act = lane < ng;
             const uint64_t mycd = act ? cand[c0 + lane] : 0ull;
+            const uint32_t myq = (uint32_t)(mycd >> PBA_OVL_Q_SHIFT);
+            const OvlCand m = ovl_decode(Rd, ref_len, ht, mycd, cfg);
             int myfr = 0;
             if constexpr (NB != 0) {
-                const OvlCand m = ovl_decode(Rd, ref_len, ht, mycd, cfg);
                 AlnOut po;
                 myfr = prefilter32(act && m.ok, ref.at(m.r_off, m.fwd ? 1 : -1), m.r_len,
-                                   fetch_of(Rd, act ? m.q : 0, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R, 0, 0, pre_t, po);
+                                   fetch_of(Rd, act ? myq : 0u, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R, 0, 0, pre_t, po);
             }
-            for (uint32_t k = 0; k < ng; ++k) {
+            // Nearly every candidate has failed by now, so the group is not walked lane by lane: lane masks say where the
+            // walk of this group ends, which failed candidates count as pairs, and only the survivors are visited.
+            const uint32_t up_q = (uint32_t)__shfl_up((int)myq, 1, PBA_WAVE);
+            const uint32_t prev_q = lane == 0 ? last_q : up_q;
+            uint64_t brk = 0;                                                   // first lane the walk does not reach
+            if (redo_in) brk = __builtin_amdgcn_ballot_w64(act && myq != only_q);           // the parked query's candidates are contiguous
+            if (c0 >= own_end) brk |= __builtin_amdgcn_ballot_w64(act && myq != prev_q);    // the run that started in the own group has ended
+            const uint32_t lim = brk ? (uint32_t)__builtin_ctzll(brk) : ng;
+            const uint64_t in = lim >= PBA_WAVE ? ~0ull : (1ull << lim) - 1ull;
+            const uint64_t live = __builtin_amdgcn_ballot_w64(act && myq != skip_q) & in;   // (a leading run of the previous group is not ours)
+            const uint64_t failed = __builtin_amdgcn_ballot_w64(myfr != 0) & live;          // failed within their first 32 rows
+            uint64_t surv = __builtin_amdgcn_ballot_w64(myfr == 0 && m.ok) & live;
+            uint32_t from = 0;
+            // failed candidates of lanes [from, to): pairs the reference aligned, unless their query was done already
+            auto count_failed = [&](uint32_t to) {
+                if (to > from) {
+                    const uint64_t f = failed & (to >= PBA_WAVE ? ~0ull : (1ull << to) - 1ull) & ~((1ull << from) - 1ull);
+                    if (f) pairs += (unsigned long long)__builtin_popcountll(f & __builtin_amdgcn_ballot_w64(myq != done_q));
+                }
+            };
+            while (surv) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(surv);
+                surv &= surv - 1ull;
+                count_failed(k);
+                from = k + 1;
                 const uint32_t c = c0 + k;
                 const uint64_t cd = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mycd >> 32), (int)k) << 32) |
                                     (uint32_t)__builtin_amdgcn_readlane((int)mycd, (int)k);
                 const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
-                if (redo_in && q != only_q) { stop = true; break; }         // the parked query's candidates are contiguous
-                if (c >= own_end && q != last_q) { stop = true; break; }    // the run that started in the own group has ended
-                last_q = q;
-                if (q == skip_q) continue;                                  // this run belongs to the previous group
                 if (q == done_q) continue;                                  // first success per (target, query) already taken
-                if (__builtin_amdgcn_readlane(myfr, (int)k)) { ++pairs; continue; }   // failed within its first 32 rows
-                const OvlCand m = ovl_decode(Rd, ref_len, ht, cd, cfg);
-                if (!m.ok) continue;
-                const PackedFetch fa = ref.at(m.r_off, m.fwd ? 1 : -1);      // a = the target in the reference role (ref_seq.h:264)
-                const PackedFetch fb = fetch_of(Rd, q, m.s_off, m.fwd ? 1 : -1);
+                const OvlCand mk = ovl_decode(Rd, ref_len, ht, cd, cfg);
+                const PackedFetch fa = ref.at(mk.r_off, mk.fwd ? 1 : -1);    // a = the target in the reference role (ref_seq.h:264)
+                const PackedFetch fb = fetch_of(Rd, q, mk.s_off, mk.fwd ? 1 : -1);
                 AlnOut o;
-                if constexpr (NB == 0) align_rowsweep(fa, m.r_len, fb, m.s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
-                else align_bitvec<NB>(fa, m.r_len, fb, m.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);
-                if (o.rc == PBA_RC_UNCERTIFIED) {                           // only in the first launch
+                if constexpr (NB == 0) align_rowsweep(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
+                else align_bitvec<NB>(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);
+                if (o.rc == PBA_RC_UNCERTIFIED) {                           // park the (target, query): resumed in a wider ring
                     done_q = q;
                     const unsigned long long slot = atomicAdd(n_redo_out, l0 ? 1ull : 0ull);
                     if (l0 && slot < redo_cap) redo_out[slot] = make_uint2(tl, c);
@@ -253,11 +280,15 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
                 ++pairs;
                 if (o.rc < 0 || o.matlen_a < cfg.overlap_min) continue;     // ref_seq.h:264-265
                 done_q = q;
-                ovl_emit(out, cap, n_out, t, q, m.j, m.fwd, m.hit, o);
+                ovl_emit(out, cap, n_out, t, q, mk.j, mk.fwd, mk.hit, o);
             }
+            count_failed(lim);
+            if (lim) last_q = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)(lim - 1));
+            if (brk) stop = true;
         }
-        atomicAdd(n_pairs, l0 ? pairs : 0ull);
+        }
     }
+    atomicAdd(n_pairs, l0 ? pairs : 0ull);
 }
 
 #endif

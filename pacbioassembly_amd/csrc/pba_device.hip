@@ -48,12 +48,12 @@ struct pba_seqs {
     uint8_t *d_packed;
     uint64_t *d_off;
     uint32_t *d_len;
-    uint32_t *d_planes;      // allocation of the two bit planes (low, then high), kPlaneSlack zero words around each
+    uint32_t *d_planes;      // allocation of the two bit planes, interleaved word by word, kPlaneSlack zero word pairs around them
     uint64_t *d_poff;        // word offset of every sequence inside a plane
     uint64_t plane_words;    // words of one plane incl. its slack
     std::vector<uint64_t> h_off;
     std::vector<uint32_t> h_len;
-    SeqSetDev dev() const { return SeqSetDev{d_packed, d_off, d_len, d_planes + kPlaneSlack, d_poff, plane_words}; }
+    SeqSetDev dev() const { return SeqSetDev{d_packed, d_off, d_len, d_planes + 2 * kPlaneSlack, d_poff}; }
 };
 
 struct pba_index {
@@ -128,7 +128,7 @@ k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_of
 // Bit planes of a packed set (dev_common.h: SeqSetDev::plane): thread w owns plane word w of the whole set.
 __global__ void __launch_bounds__(256)
 k_make_planes(const uint8_t *packed, const uint64_t *off, const uint32_t *len, const uint64_t *poff, uint32_t n,
-              uint64_t total_words, uint32_t *plane_lo, uint64_t hi_words) {
+              uint64_t total_words, uint32_t *plane) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= total_words) return;
     uint32_t lo = 0, hi = n;            // last s with poff[s] <= w
@@ -145,9 +145,10 @@ k_make_planes(const uint8_t *packed, const uint64_t *off, const uint32_t *len, c
         const uint32_t valid = L - (uint32_t)(k * 32);
         if (valid < 32) { plo &= (1u << valid) - 1u; phi &= (1u << valid) - 1u; }   // nothing of the neighbour's bytes
     }
-    plane_lo[w] = plo;
-    plane_lo[w + hi_words] = phi;
+    plane[2 * w] = plo;                  // the two planes side by side: one line serves both (align_bitvec.h: load_planes32)
+    plane[2 * w + 1] = phi;
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // kernels: alignment of explicit pairs
@@ -665,7 +666,7 @@ static int seqs_planes(pba_ctx *ctx, pba_seqs *s) {
         const uint64_t blocks = (w + 255) / 256;
         if (blocks > 0x7FFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "sequence set too large");
         hipLaunchKernelGGL(k_make_planes, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, s->d_packed, s->d_off, s->d_len,
-                           s->d_poff, s->n, w, s->d_planes + kPlaneSlack, s->plane_words);
+                           s->d_poff, s->n, w, s->d_planes + 2 * kPlaneSlack);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));      // poff (host vector) must outlive the copy

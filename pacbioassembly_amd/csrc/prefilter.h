@@ -27,18 +27,8 @@ struct PreThresholds {
     }
 };
 
-// Returns the first failing row (11..32) of the pair this LANE holds, or 0 when rows 11..32 all pass or the
-// prefilter does not apply (a sequence shorter than 32 after the reference's length clipping, the size guard) --
-// then the full aligner decides.  `active`: lanes without a pair must pass false (they return 0).
-__device__ __forceinline__ int prefilter32(bool active, const PackedFetch &fa, int la, const PackedFetch &fb, int lb,
-                                           double R, int maxn, int maxm, const PreThresholds &T, AlnOut &o) {
-    aln_params(la, lb, R, o);
-    if (!active) return 0;
-    if (maxn > 0 && (o.len_a >= maxn + maxm || o.max_dst >= maxm)) return 0;   // seq_aligner.h:104-107: the caller's path
-    if (o.len_a < PBA_PRE_ROWS || o.len_b < PBA_PRE_ROWS) return 0;
-    uint32_t alo, ahi, blo, bhi;
-    load_planes32(fa, 0, alo, ahi);            // rows: a[0..31]
-    load_planes32(fb, 0, blo, bhi);            // columns: b[0..31], bit k = column k+1
+// the sweep itself: a's first 32 elements as rows (alo / ahi), b's first 32 as columns (blo / bhi: bit k = column k+1)
+__device__ __forceinline__ int prefilter32_planes(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, const PreThresholds &T) {
     uint32_t Pv = ~0u, Mv = 0u;                // column 0: D(i,0) = i
     int score = 0, fr = 0;                     // score = D(j,j)
 #pragma unroll
@@ -58,6 +48,26 @@ __device__ __forceinline__ int prefilter32(bool active, const PackedFetch &fa, i
         if (k + 1 > 10 && fr == 0 && score > T.t[k + 1]) fr = k + 1;
     }
     return fr;
+}
+
+// whether the prefilter applies to a pair of these accessor lengths (else the full aligner decides)
+__device__ __forceinline__ bool prefilter32_applies(bool active, int la, int lb, double R, int maxn, int maxm, AlnOut &o) {
+    aln_params(la, lb, R, o);
+    if (!active) return false;
+    if (maxn > 0 && (o.len_a >= maxn + maxm || o.max_dst >= maxm)) return false;   // seq_aligner.h:104-107: the caller's path
+    return o.len_a >= PBA_PRE_ROWS && o.len_b >= PBA_PRE_ROWS;
+}
+
+// Returns the first failing row (11..32) of the pair this LANE holds, or 0 when rows 11..32 all pass or the
+// prefilter does not apply (a sequence shorter than 32 after the reference's length clipping, the size guard) --
+// then the full aligner decides.  `active`: lanes without a pair must pass false (they return 0).
+__device__ __forceinline__ int prefilter32(bool active, const PackedFetch &fa, int la, const PackedFetch &fb, int lb,
+                                           double R, int maxn, int maxm, const PreThresholds &T, AlnOut &o) {
+    if (!prefilter32_applies(active, la, lb, R, maxn, maxm, o)) return 0;
+    uint32_t alo, ahi, blo, bhi;
+    load_planes32(fa, 0, alo, ahi);            // rows: a[0..31]
+    load_planes32(fb, 0, blo, bhi);            // columns: b[0..31], bit k = column k+1
+    return prefilter32_planes(alo, ahi, blo, bhi, T);
 }
 
 #endif
