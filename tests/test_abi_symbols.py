@@ -41,3 +41,25 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "pba_oracle" not in txt and "oraclelib" not in txt and "orc_" not in txt, f
+
+
+def test_examples_build_against_the_c_abi_and_refuse_to_run_without_a_gpu(lib, tmp_path):
+    """examples/*.cpp are plain C++ over include/pba.h: they compile and link with g++ (no HIP at the call site), and
+    without a gfx950 device they stop with PBA_E_NODEVICE instead of computing anything on the CPU."""
+    import subprocess
+    import torch
+    libdir = os.path.join(ROOT, "pacbioassembly_amd", "lib")
+    for name in ("locator_gpu", "spaced_seed_gpu"):
+        exe = str(tmp_path / name)
+        subprocess.run(["g++", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                        os.path.join(ROOT, "examples", name + ".cpp"), "-L", libdir, "-lpba", f"-Wl,-rpath,{libdir}"], check=True)
+    if torch.cuda.is_available():
+        return
+    (tmp_path / "c.txt").write_text("ACGT" * 100 + "\n")
+    (tmp_path / "s.txt").write_text("111*11*11*1*1111\n")
+    (tmp_path / "r.bin").write_bytes(b"")
+    r = subprocess.run([str(tmp_path / "locator_gpu"), str(tmp_path / "c.txt"), "111*11*11*1*1111"], input=b"ACGT\n", capture_output=True)
+    assert r.returncode != 0 and r.stdout == b"" and b"device" in r.stderr.lower()
+    r = subprocess.run([str(tmp_path / "spaced_seed_gpu"), "-f", str(tmp_path / "c.txt"), str(tmp_path / "r.bin"), str(tmp_path / "s.txt")],
+                       capture_output=True)
+    assert r.returncode != 0 and r.stdout == b""
