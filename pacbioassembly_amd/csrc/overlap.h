@@ -82,7 +82,7 @@ k_ovl_presence(const uint64_t *ent, uint64_t n, uint32_t *bits) {
 #define PBA_OVL_SUB 64
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_ovl_scan(IndexDev probes, const uint32_t *presence, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2,
+k_ovl_scan(IndexDev probes, KeyDir kd, const uint32_t *presence, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2,
            uint32_t sub_mul, int shift, uint32_t *cnt_or_cursor, uint64_t *cand) {
     const uint32_t tl = blockIdx.x;
     if (tl >= n_targets) return;
@@ -103,7 +103,8 @@ k_ovl_scan(IndexDev probes, const uint32_t *presence, SeqSetDev Rd, uint32_t t_l
         const uint32_t h = ovl_pres_slot(key);
         if (!((presence[h >> 5] >> (h & 31)) & 1u)) continue;           // no probe has this key
         uint32_t beg, n;
-        ix_find(probes, key, beg, n);
+        if (kd.dir) dir_find(kd, probes.ent, key, beg, n);
+        else ix_find(probes, key, beg, n);
         for (uint32_t h = 0; h < n; ++h) {
             const uint32_t pid = (uint32_t)probes.ent[beg + h];
             const uint32_t q = pid / t2;

@@ -1735,13 +1735,35 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     if (pix->n_entries)
         hipLaunchKernelGGL(k_ovl_presence, dim3((uint32_t)((pix->n_entries + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const uint64_t *)pix->d_ent, (uint64_t)pix->n_entries, d_pres.as<uint32_t>());
+    // a direct-address directory of the probe keys (seed_index.h: KeyDir), when the mask's care bits allow one
+    KeyDir kd;
+    memset(&kd, 0, sizeof kd);
+    DevBuf d_dir;
+    const int care = __builtin_popcount(mask);
+    if (pix->n_entries && pix->n_entries < 0xFFFFFFFFull && care <= PBA_DIR_MAX_BITS) {
+        kd.mask = mask; kd.n_entries = (uint32_t)pix->n_entries;
+        uint32_t m = mask, mk = ~m << 1;                         // Hacker's Delight 7-4: the move masks of compress(x, m)
+        for (int i = 0; i < 5; ++i) {
+            uint32_t mp = mk ^ (mk << 1);
+            mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
+            const uint32_t mv = mp & m;
+            kd.mv[i] = mv;
+            m = (m ^ mv) | (mv >> (1 << i));
+            mk &= ~mp;
+        }
+        HIPCHK(hipMalloc(&d_dir.p, sizeof(uint32_t) << care));
+        HIPCHK(hipMemsetAsync(d_dir.p, 0xFF, sizeof(uint32_t) << care, ctx->stream));
+        hipLaunchKernelGGL(k_dir_build, dim3((kd.n_entries + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)pix->d_ent,
+                           kd.n_entries, kd, d_dir.as<uint32_t>());
+        kd.dir = d_dir.as<uint32_t>();
+    }
     HIPCHK(hipMalloc(&d_off.p, sizeof(uint32_t) * (nt + 1)));
     // count per (target, bucket of consecutive queries): PBA_OVL_SUB buckets per target
     const uint64_t nsub = (uint64_t)nt * PBA_OVL_SUB;
     const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // bucket = umulhi(q, sub_mul)
     DevBuf d_sub;
     HIPCHK(hipMalloc(&d_sub.p, sizeof(uint32_t) * (nsub + 1)));
-    hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), d_pres.as<uint32_t>(), reads->dev(),
+    hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), kd, d_pres.as<uint32_t>(), reads->dev(),
                        t_lo, nt, t2, sub_mul, 0, d_sub.as<uint32_t>(), (uint64_t *)nullptr);
     std::vector<uint32_t> h_sub(nsub + 1), h_cnt(nt + 1), h_off(nt + 1);
     HIPCHK(hipMemcpyAsync(h_sub.data(), d_sub.p, sizeof(uint32_t) * nsub, hipMemcpyDeviceToHost, ctx->stream));
@@ -1788,7 +1810,7 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     HIPCHK(hipMemcpyAsync(d_poff.p, h_poff.data(), sizeof(uint32_t) * (npiece + 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_cur.p, h_poff.data(), sizeof(uint32_t) * (npiece + 1), hipMemcpyHostToDevice, ctx->stream));
     if (total) {
-        hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), d_pres.as<uint32_t>(),
+        hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), kd, d_pres.as<uint32_t>(),
                            reads->dev(), t_lo, nt, t2, sub_mul, shift, d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
         (void)hipEventRecord(ctx->ev[3], ctx->stream);
         // 3. sort every piece = the reference's try order inside every (target, query); the pieces of a target in

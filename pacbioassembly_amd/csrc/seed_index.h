@@ -51,28 +51,65 @@ __device__ __forceinline__ uint32_t ix_lower_bound(const uint64_t *ent, uint32_t
     return lo;
 }
 
-// hash_table::find: run [beg, beg+cnt) of `key` in reference list order
-__device__ __forceinline__ void ix_find(const IndexDev &ix, uint32_t key, uint32_t &beg, uint32_t &cnt) {
-    const uint32_t p = ix_part(key, ix.logP);
-    const uint32_t lo = ix.part_off[p], hi = ix.part_off[p + 1];
-    beg = ix_lower_bound(ix.ent, lo, hi, (uint64_t)key << 32);
-    // the end of the run: almost always 0-2 entries further on, so gallop from `beg` (1, 2, 4, ... entries) and finish with
-    // a binary search inside the last stride -- a second full-depth search would double the dependent loads of a probe
+// end of the run of `key` that starts at entry `beg` (entries up to `hi` may belong to it): almost always 0-2 entries
+// further on, so gallop from `beg` (1, 2, 4, ... entries) and finish with a binary search inside the last stride -- a
+// second full-depth search would double the dependent loads of a probe
+__device__ __forceinline__ uint32_t ix_run_end(const uint64_t *ent, uint32_t beg, uint32_t hi, uint32_t key) {
     uint32_t a = beg, step = 1;
-    while (a < hi && (uint32_t)(ix.ent[a] >> 32) == key) {
+    while (a < hi && (uint32_t)(ent[a] >> 32) == key) {
         const uint32_t nxt = a + step < hi ? a + step : hi;
-        if (nxt < hi && (uint32_t)(ix.ent[nxt] >> 32) == key) { a = nxt; step <<= 1; }
+        if (nxt < hi && (uint32_t)(ent[nxt] >> 32) == key) { a = nxt; step <<= 1; }
         else {                                   // the run ends in (a, nxt]
             uint32_t l = a + 1, h = nxt;
             while (l < h) {
                 const uint32_t mid = l + ((h - l) >> 1);
-                if ((uint32_t)(ix.ent[mid] >> 32) == key) l = mid + 1; else h = mid;
+                if ((uint32_t)(ent[mid] >> 32) == key) l = mid + 1; else h = mid;
             }
             a = l;
             break;
         }
     }
-    cnt = a - beg;
+    return a;
+}
+
+// hash_table::find: run [beg, beg+cnt) of `key` in reference list order
+__device__ __forceinline__ void ix_find(const IndexDev &ix, uint32_t key, uint32_t &beg, uint32_t &cnt) {
+    const uint32_t p = ix_part(key, ix.logP);
+    const uint32_t lo = ix.part_off[p], hi = ix.part_off[p + 1];
+    beg = ix_lower_bound(ix.ent, lo, hi, (uint64_t)key << 32);
+    cnt = ix_run_end(ix.ent, beg, hi, key) - beg;
+}
+
+// Direct-address directory over an index (the all-vs-all scan looks a key up for every position of every read: the
+// partition's binary search is ~15 dependent loads, this is one).  A key under a mask of w care bits is one of 2^w
+// values: dir[compress(key)] = first entry of the key's run, or PBA_DIR_EMPTY.  compress() gathers the care bits
+// (Hacker's Delight 7-4, the five move masks precomputed on the host for the mask).
+#define PBA_DIR_EMPTY 0xFFFFFFFFu
+#define PBA_DIR_MAX_BITS 26
+struct KeyDir {
+    const uint32_t *dir;     // nullptr: no directory (mask too heavy), fall back to ix_find
+    uint32_t mask, mv[5];
+    uint32_t n_entries;
+};
+__device__ __forceinline__ uint32_t dir_compress(const KeyDir &d, uint32_t x) {
+    x &= d.mask;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t t = x & d.mv[i];
+        x = (x ^ t) | (t >> (1 << i));
+    }
+    return x;
+}
+__device__ __forceinline__ void dir_find(const KeyDir &d, const uint64_t *ent, uint32_t key, uint32_t &beg, uint32_t &cnt) {
+    beg = d.dir[dir_compress(d, key)];
+    cnt = beg == PBA_DIR_EMPTY ? 0u : ix_run_end(ent, beg, d.n_entries, key) - beg;
+}
+__global__ void __launch_bounds__(256)
+k_dir_build(const uint64_t *ent, uint32_t n, KeyDir d, uint32_t *dir) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = (uint32_t)(ent[i] >> 32);
+    if (i == 0 || (uint32_t)(ent[i - 1] >> 32) != key) dir[dir_compress(d, key)] = i;   // equal keys are contiguous (same partition, sorted)
 }
 
 // One scan segment: positions [lo, hi) of a sequence, visited ascending (ord = ord0 + pos - lo)
