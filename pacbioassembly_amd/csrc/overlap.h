@@ -124,6 +124,19 @@ k_ovl_scan(IndexDev probes, KeyDir kd, const uint32_t *presence, SeqSetDev Rd, u
     }
 }
 
+// work item i of a call = (target, first candidate of its group of 64): item_pre[t] = items of the targets before t
+__global__ void __launch_bounds__(256)
+k_ovl_items(const uint32_t *item_pre, const uint32_t *cand_off, uint32_t n_targets, uint32_t n_items, uint2 *items) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    uint32_t lo = 0, hi = n_targets;                // last target t with item_pre[t] <= i
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (item_pre[mid] <= i) lo = mid; else hi = mid;
+    }
+    items[i] = make_uint2(lo, cand_off[lo] + (i - item_pre[lo]) * PBA_WAVE);
+}
+
 struct OvlCfg {
     double R;
     int overlap_min;

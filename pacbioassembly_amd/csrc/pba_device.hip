@@ -1844,13 +1844,21 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     DevBuf d_redo, d_items;
     const uint64_t redo_cap = std::max<uint64_t>(1024, total / 4);
     HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2) * redo_cap));
-    std::vector<uint2> h_items;                                  // work items: (target, first candidate of a group of 64)
-    h_items.reserve((size_t)(total / PBA_WAVE) + nt);
-    for (uint32_t i = 0; i < nt; ++i)
-        for (uint32_t c = h_off[i]; c < h_off[i] + h_cnt[i]; c += PBA_WAVE) h_items.push_back(make_uint2(i, c));
-    HIPCHK(hipMalloc(&d_items.p, sizeof(uint2) * (h_items.size() + 1)));
-    if (!h_items.empty())
-        HIPCHK(hipMemcpyAsync(d_items.p, h_items.data(), sizeof(uint2) * h_items.size(), hipMemcpyHostToDevice, ctx->stream));
+    // work items: (target, first candidate of a group of 64), expanded on the device from the per-target item counts
+    // (a million reads make 22 M items per call: building and copying them from the host took longer than a scan pass)
+    std::vector<uint32_t> h_ipre(nt + 1);
+    uint64_t n_items64 = 0;
+    for (uint32_t i = 0; i < nt; ++i) { h_ipre[i] = (uint32_t)n_items64; n_items64 += (h_cnt[i] + PBA_WAVE - 1) / PBA_WAVE; }
+    if (n_items64 >= 0xFFFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: too many work items per call, use a smaller target range");
+    h_ipre[nt] = (uint32_t)n_items64;
+    DevBuf d_ipre;
+    HIPCHK(hipMalloc(&d_ipre.p, sizeof(uint32_t) * (nt + 1)));
+    HIPCHK(hipMemcpyAsync(d_ipre.p, h_ipre.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMalloc(&d_items.p, sizeof(uint2) * (n_items64 + 1)));
+    if (n_items64)
+        hipLaunchKernelGGL(k_ovl_items, dim3((uint32_t)((n_items64 + 255) / 256)), dim3(256), 0, ctx->stream, d_ipre.as<uint32_t>(),
+                           d_off.as<uint32_t>(), nt, (uint32_t)n_items64, d_items.as<uint2>());
+    HIPCHK(hipStreamSynchronize(ctx->stream));                   // h_ipre must outlive its copy
     // one launch of the walk: items [lo, hi) of the group list (redo_in == nullptr) or n_redo parked runs
     auto walk = [&](int nb, const uint2 *items, uint32_t n_items, int full_band, const uint2 *redo_in) -> int {
         HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
@@ -1895,7 +1903,7 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     // narrow-then-redo, and if most of its successful runs had to be parked the rest starts wider: in the widest ring
     // below the reference band's (its first-pass window takes all the room that ring has, bv_pass1_w -- at 15 kb NB = 3
     // holds a window of 4 072, which certifies every overlap but the longest), or straight at the reference band.
-    const size_t n_all = h_items.size();
+    const size_t n_all = (size_t)n_items64;
     size_t sample_min = 4096;
     if (const char *e = getenv("PBA_OVL_SAMPLE_MIN")) sample_min = (size_t)std::max(1L, atol(e));   // test hook: small inputs through the sampled decision
     const size_t n_sample = pl.nb1 == 0 ? n_all : std::min(n_all, std::max<size_t>(sample_min, n_all / 32));
