@@ -1819,7 +1819,8 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
         while (pow2 < biggest) pow2 <<= 1;
         for (uint64_t p0 = 0; p0 < npiece; p0 += 0x40000000ull) {  // (grid dimension limit)
             const uint32_t chunk = (uint32_t)std::min<uint64_t>(npiece - p0, 0x40000000ull);
-            hipLaunchKernelGGL(k_part_sort, dim3(chunk), dim3(256), sizeof(uint64_t) * pow2, ctx->stream, d_cand.as<uint64_t>(),
+            // (a big piece takes most of a CU's LDS, so its workgroup is the only one there: 1 024 threads keep the CU busy)
+            hipLaunchKernelGGL(k_part_sort, dim3(chunk), dim3(pow2 >= 4096 ? 1024 : 256), sizeof(uint64_t) * pow2, ctx->stream, d_cand.as<uint64_t>(),
                                d_poff.as<uint32_t>() + p0);
         }
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -300,7 +300,7 @@ k_ent_scatter(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cursor, u
 }
 
 // pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
-__global__ void __launch_bounds__(256) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
+__global__ void __launch_bounds__(1024) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
     extern __shared__ __align__(16) uint64_t s_ent[];
     const uint32_t lo = part_off[blockIdx.x], n = part_off[blockIdx.x + 1] - lo;
     if (n < 2 || n > PBA_IX_LDS_SORT_CAP) return;     // oversize partitions take the global path
