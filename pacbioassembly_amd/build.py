@@ -2,9 +2,13 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
 pacbioassembly_amd/lib/libpba.so is git-ignored but travels to the GPU box with the snapshot.
+Every translation unit is compiled to its own object (in parallel, only when it or a header changed) and the
+objects are linked into one shared library.
 """
 from __future__ import annotations
 
+import concurrent.futures
+import hashlib
 import os
 import shutil
 import subprocess
@@ -14,11 +18,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libpba.so")
 
-SOURCES = ["pba_device.hip", "pba_codec.cpp", "pba_synth.cpp"]
-HEADERS = ["dev_common.h", "align_rowsweep.h", "align_bitvec.h", "align_bvtrace.h", "prefilter.h", "consensus.h", "seed_index.h",
-           "overlap.h", "pba_internal.h"]
+SOURCES = ["pba_core.hip", "pba_align.hip", "pba_drivers.hip", "pba_overlap.hip", "pba_cons.hip", "pba_codec.cpp",
+           "pba_synth.cpp"]
 
 
 def _hipcc() -> str:
@@ -28,30 +32,58 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libpba.so cannot be built (there is no CPU fallback)")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "pba.h")]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "pba.h")]
+
+
+def _flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            "-ffp-contract=off",            # i*R and len*(1-R) must round exactly like the reference's FP64
+            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+            "-I", os.path.join(ROOT, "include"), "-I", CSRC] + os.environ.get("PBA_EXTRA_CFLAGS", "").split()
+
+
+def source_digest() -> str:
+    """Digest of everything the library is built from (bench.py ties committed profile figures to it)."""
+    h = hashlib.sha256()
+    for p in [os.path.join(CSRC, s) for s in SOURCES] + _headers():
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    h.update(" ".join(_flags()[:8]).encode())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP/C++ source into one shared library; returns its path."""
-    if not force and not _stale():
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-ffp-contract=off",            # i*R and len*(1-R) must round exactly like the reference's FP64
-        "-fgpu-rdc" if False else "-fno-gpu-rdc",
-        "-Wall", "-Wno-unused-function",
-        "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-        "-o", LIB,
-    ] + os.environ.get("PBA_EXTRA_CFLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    """Compile every HIP/C++ source and link one shared library; returns its path."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(p) for p in srcs + _headers()) \
+            and not os.environ.get("PBA_EXTRA_CFLAGS"):
+        return LIB                      # (the objects do not travel to the GPU box; the library does)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc, flags = _hipcc(), _flags()
+    newest_hdr = max(os.path.getmtime(h) for h in _headers())
+    stamp = os.path.join(OBJDIR, "flags.txt")
+    flag_text = " ".join(flags)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(OBJDIR, s + ".o") for s in SOURCES]
+    if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs + ["-lpthread"])
+        open(stamp, "w").write(flag_text)
     return LIB
 
 

@@ -38,7 +38,7 @@ __device__ __forceinline__ void cons_bump(unsigned long long *box, int c, unsign
 }
 
 // boxes [first, first+len) <- vote_box(text[k], weight) (ref_seq.h:118: selection(c, n), total(1)); text copied too
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_cons_fill(ConsDev C, int first, int len, const char *text, int weight) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= len) return;
@@ -50,7 +50,7 @@ k_cons_fill(ConsDev C, int first, int len, const char *text, int weight) {
 }
 
 // apply_edits (ref_seq.h:25-41) for n scripts, one wavefront each.  pos is relative to `beg`.
-__global__ void __launch_bounds__(PBA_WAVE)
+static __global__ void __launch_bounds__(PBA_WAVE)
 k_cons_elect(ConsDev C, int beg, int pre, int post, uint32_t n, const int *pos, const uint8_t *fwd, const uint8_t *ops,
              const char *vals, const unsigned long long *ops_off, const int *nedit) {
     const uint32_t q = blockIdx.x;
@@ -113,7 +113,7 @@ struct VoteSink {
 };
 
 // evolve: [pre, post) of `in` -> boxes and text from index `beg` of `out`; *n_out = boxes kept
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_cons_evolve(ConsDev in, ConsDev out, int pre, int post, int beg, int *n_out) {
     __shared__ int scan[1024];
     __shared__ int carry;

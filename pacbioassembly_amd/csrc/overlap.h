@@ -31,7 +31,7 @@
 #define PBA_OVL_Q_SHIFT (PBA_OVL_ORD_BITS + PBA_OVL_JD_BITS)
 
 // probe id = query * t2 + 2*j + (backward ? 1 : 0); t2 = 2 * max_trial
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_probe_emit(SeqSetDev Rd, uint32_t q_lo, uint32_t n_queries, uint32_t t2, uint32_t mask, uint64_t *out,
              unsigned long long cap, unsigned long long *counter) {
     const uint64_t lid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,7 +65,7 @@ struct HeadTail {
 // load spares the scan most of its dependent binary searches.
 #define PBA_OVL_PRES_LOG 26
 __device__ __forceinline__ uint32_t ovl_pres_slot(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - PBA_OVL_PRES_LOG); }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_ovl_presence(const uint64_t *ent, uint64_t n, uint32_t *bits) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -81,7 +81,7 @@ k_ovl_presence(const uint64_t *ent, uint64_t n, uint32_t *bits) {
 // from cursor[(t - t_lo) * (SUB >> shift) + p] on.
 #define PBA_OVL_SUB 64
 template <bool FILL>
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_ovl_scan(IndexDev probes, KeyDir kd, const uint32_t *presence, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2,
            uint32_t sub_mul, int shift, uint32_t *cnt_or_cursor, uint64_t *cand) {
     const uint32_t tl = blockIdx.x;
@@ -125,7 +125,7 @@ k_ovl_scan(IndexDev probes, KeyDir kd, const uint32_t *presence, SeqSetDev Rd, u
 }
 
 // work item i of a call = (target, first candidate of its group of 64): item_pre[t] = items of the targets before t
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_ovl_items(const uint32_t *item_pre, const uint32_t *cand_off, uint32_t n_targets, uint32_t n_items, uint2 *items) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
 // Second launch (redo_in != nullptr, full_band): one parked (target, query) per work item, resumed at the parked
 // candidate with the reference band until the first success or the end of the query's candidates.
 template <int NB>
-__global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 4 ? 6 : 3))
+static __global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 4 ? 6 : 3))
 k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off,
            const uint64_t *cand, OvlCfg cfg, int full_band, const uint2 *redo_in, uint2 *redo_out, unsigned long long redo_cap,
            unsigned long long *n_redo_out, pba_overlap *out, unsigned long long cap, unsigned long long *n_out,

@@ -1,0 +1,607 @@
+// pba_core.hip -- context, sequence sets and the seed-hit index: kernels and the device half of the C ABI (include/pba.h).
+// One process per GPU, one pba_ctx per process, one HIP stream per ctx.  Everything here fails loudly
+// (PBA_E_NODEVICE / PBA_E_HIP): there is no CPU path behind these entry points.
+#include "pba_host.h"
+#include "pba_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// kernels: packing
+// ---------------------------------------------------------------------------------------------
+// ASCII -> 2-bit, 16 chars per thread into one packed dword.  Thread t owns packed dword t of the
+// whole set; its sequence is found by bisection over the (16-byte aligned) packed offsets.
+__global__ void __launch_bounds__(256)
+k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_off, const uint32_t *len, uint32_t n,
+            uint64_t total_dwords, uint8_t *packed, int strict, uint32_t *bad) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_dwords) return;
+    const uint64_t byte = t * 4;
+    uint32_t lo = 0, hi = n;            // last s with pk_off[s] <= byte
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pk_off[mid] <= byte) lo = mid; else hi = mid;
+    }
+    const uint32_t s = lo;
+    const uint32_t L = len[s];
+    const uint64_t w = (byte - pk_off[s]) >> 2;          // dword index inside the sequence
+    if (w * 16 >= L) return;                             // alignment padding
+    const uint8_t *src = text + text_off[s] + w * 16;
+    const uint32_t nb = (uint32_t)min((uint64_t)16, (uint64_t)L - w * 16);
+    uint32_t word = 0, notacgt = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t ch = src[k];
+        const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;   // C2I, dna_seq.h:21
+        notacgt |= (code == 3u && ch != 'T');
+        word |= code << (8 * (k >> 2) + 6 - 2 * (k & 3));   // byte k/4, first base in bits 7:6
+    }
+    *reinterpret_cast<uint32_t *>(packed + byte) = word;    // padding bytes of the last dword stay 0
+    if (notacgt) atomicOr(bad, 1u);
+}
+
+// Bit planes of a packed set (dev_common.h: SeqSetDev::plane): thread w owns plane word w of the whole set.
+__global__ void __launch_bounds__(256)
+k_make_planes(const uint8_t *packed, const uint64_t *off, const uint32_t *len, const uint64_t *poff, uint32_t n,
+              uint64_t total_words, uint32_t *plane) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= total_words) return;
+    uint32_t lo = 0, hi = n;            // last s with poff[s] <= w
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (poff[mid] <= w) lo = mid; else hi = mid;
+    }
+    const uint32_t s = lo;
+    const uint64_t k = w - poff[s];     // word index inside the sequence
+    const uint32_t L = len[s];
+    uint32_t plo = 0, phi = 0;
+    if (k * 32 < L) {
+        planes_from_packed(packed + off[s], (int)(k * 32), plo, phi);
+        const uint32_t valid = L - (uint32_t)(k * 32);
+        if (valid < 32) { plo &= (1u << valid) - 1u; phi &= (1u << valid) - 1u; }   // nothing of the neighbour's bytes
+    }
+    plane[2 * w] = plo;                  // the two planes side by side: one line serves both (align_bitvec.h: load_planes32)
+    plane[2 * w + 1] = phi;
+}
+
+
+static void tu_attrs() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    PBA_BIG_LDS(k_part_sort);
+}
+
+extern "C" {
+
+int pba_ctx_create(int device_id, pba_ctx **out) {
+    if (!out) return PBA_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PBA_E_NODEVICE;
+    if (device_id < 0 || device_id >= ndev) return PBA_E_NODEVICE;
+    pba_ctx *ctx = new (std::nothrow) pba_ctx();
+    if (!ctx) return PBA_E_NOMEM;
+    ctx->device = device_id;
+    ctx->err[0] = 0;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
+        delete ctx;
+        return PBA_E_NODEVICE;
+    }
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {   // the code object holds gfx950 ISA only
+        delete ctx;
+        return PBA_E_NODEVICE;
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PBA_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (int i = 0; i < 6; ++i)
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PBA_E_HIP; }
+    memset(&ctx->prof, 0, sizeof ctx->prof);
+    if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
+    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+    // (kernels that take more than the default 64 KB of dynamic LDS are given the attribute by the translation unit
+    // that launches them: tu_attrs() in each .hip)
+    *out = ctx;
+    return PBA_OK;
+}
+
+void pba_ctx_destroy(pba_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->own_stream);
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipFree(ctx->d_queue);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    delete ctx;
+}
+
+const char *pba_ctx_error(const pba_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int pba_ctx_set_stream(pba_ctx *ctx, void *hip_stream) {
+    if (!ctx) return PBA_E_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PBA_OK;
+}
+
+int pba_ctx_sync(pba_ctx *ctx) {
+    if (!ctx) return PBA_E_INVALID;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_ctx_last_profile(const pba_ctx *ctx, pba_profile *out) {
+    if (!ctx || !out) return PBA_E_INVALID;
+    *out = ctx->prof;
+    return PBA_OK;
+}
+
+int pba_ctx_device_info(const pba_ctx *ctx, char *name, size_t cap, int *n_cu, int *clock_mhz, uint64_t *hbm) {
+    if (!ctx) return PBA_E_INVALID;
+    if (name && cap) snprintf(name, cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
+    if (hbm) *hbm = (uint64_t)ctx->prop.totalGlobalMem;
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: sequence sets
+// ---------------------------------------------------------------------------------------------
+static int seqs_alloc(pba_ctx *ctx, pba_seqs *s, uint64_t packed_bytes) {
+    s->packed_bytes = packed_bytes;
+    HIPCHK(hipMalloc((void **)&s->d_alloc, packed_bytes + 2 * kSlack));
+    HIPCHK(hipMemsetAsync(s->d_alloc, 0, packed_bytes + 2 * kSlack, ctx->stream));
+    s->d_packed = s->d_alloc + kSlack;
+    HIPCHK(hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (s->n + 1)));
+    HIPCHK(hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (s->n + 1)));
+    HIPCHK(hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * s->n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s->d_len, s->h_len.data(), sizeof(uint32_t) * s->n, hipMemcpyHostToDevice, ctx->stream));
+    return PBA_OK;
+}
+
+// the bit planes of a set whose packed bytes, offsets and lengths are on the device (enqueued on the ctx's stream)
+static int seqs_planes(pba_ctx *ctx, pba_seqs *s) {
+    std::vector<uint64_t> poff(s->n + 1);
+    uint64_t w = 0;
+    for (uint32_t i = 0; i < s->n; ++i) { poff[i] = w; w += ((uint64_t)s->h_len[i] + 31) / 32; }
+    poff[s->n] = w;
+    s->plane_words = w + 2 * kPlaneSlack;
+    HIPCHK(hipMalloc((void **)&s->d_planes, s->plane_words * 2 * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(s->d_planes, 0, s->plane_words * 2 * sizeof(uint32_t), ctx->stream));
+    HIPCHK(hipMalloc((void **)&s->d_poff, sizeof(uint64_t) * (s->n + 1)));
+    HIPCHK(hipMemcpyAsync(s->d_poff, poff.data(), sizeof(uint64_t) * (s->n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (w) {
+        const uint64_t blocks = (w + 255) / 256;
+        if (blocks > 0x7FFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "sequence set too large");
+        hipLaunchKernelGGL(k_make_planes, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, s->d_packed, s->d_off, s->d_len,
+                           s->d_poff, s->n, w, s->d_planes + 2 * kPlaneSlack);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // poff (host vector) must outlive the copy
+    return PBA_OK;
+}
+
+void pba_seqs_destroy(pba_seqs *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->d_poff) (void)hipFree(s->d_poff);
+    if (s->d_alloc) (void)hipFree(s->d_alloc);
+    if (s->d_off) (void)hipFree(s->d_off);
+    if (s->d_len) (void)hipFree(s->d_len);
+    delete s;
+}
+
+// shared tail of the two text constructors: d_text / d_toff are on the device, h_toff on the host
+static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff, const uint64_t *h_toff, uint32_t n,
+                     int strict, pba_seqs **out) {
+    pba_seqs *s = new (std::nothrow) pba_seqs();
+    if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
+    s->ctx = ctx; s->n = n; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr; s->d_planes = nullptr; s->d_poff = nullptr; s->plane_words = 0;
+    s->h_off.resize(n + 1); s->h_len.resize(n + 1);
+    uint64_t pk = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (h_toff[i + 1] < h_toff[i] || h_toff[i + 1] - h_toff[i] > 0x7FFFFFF0ull) {
+            delete s;
+            PBA_FAIL(PBA_E_INVALID, "offsets must be non-decreasing and each sequence < 2^31 bases");
+        }
+        const uint32_t L = (uint32_t)(h_toff[i + 1] - h_toff[i]);
+        s->h_off[i] = pk; s->h_len[i] = L;
+        s->max_len = std::max(s->max_len, L);
+        pk += (((uint64_t)L + 3) / 4 + 15) & ~15ull;     // every sequence starts 16-byte aligned
+    }
+    s->h_off[n] = pk; s->h_len[n] = 0;
+    int st = seqs_alloc(ctx, s, pk);
+    if (st != PBA_OK) { pba_seqs_destroy(s); return st; }
+    DevBuf bad;
+    if (hipMalloc(&bad.p, 4) != hipSuccess) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_NOMEM, "hipMalloc"); }
+    (void)hipMemsetAsync(bad.p, 0, 4, ctx->stream);
+    // the kernel bisects over n+1 offsets: upload the end offset too
+    (void)hipMemcpyAsync(s->d_off + n, &s->h_off[n], sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    const uint64_t total_dwords = pk / 4;
+    if (total_dwords) {
+        const uint64_t blocks = (total_dwords + 255) / 256;
+        if (blocks > 0x7FFFFFFFull) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_TOOLONG, "sequence set too large"); }
+        hipLaunchKernelGGL(k_pack_text, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_text, d_toff, s->d_off,
+                           s->d_len, n, total_dwords, s->d_packed, strict, bad.as<uint32_t>());
+    }
+    uint32_t h_bad = 0;
+    hipError_t e = hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "k_pack_text", e); }
+    if (strict && h_bad) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_ALPHABET, "pba_seqs_from_text"); }
+    s->non_acgt = h_bad != 0;
+    st = seqs_planes(ctx, s);
+    if (st != PBA_OK) { pba_seqs_destroy(s); return st; }
+    *out = s;
+    return PBA_OK;
+}
+
+int pba_seqs_from_text(pba_ctx *ctx, const char *text, const uint64_t *offsets, uint32_t n, int strict_acgt,
+                       pba_seqs **out) {
+    if (!ctx || !offsets || !out || (!text && n && offsets[n] > offsets[0])) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t total = n ? offsets[n] : 0;
+    DevBuf d_text, d_toff;
+    HIPCHK(hipMalloc(&d_text.p, total + kSlack));
+    HIPCHK(hipMalloc(&d_toff.p, sizeof(uint64_t) * (n + 1)));
+    if (total) HIPCHK(hipMemcpyAsync(d_text.p, text, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_toff.p, offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    return seqs_pack(ctx, d_text.as<uint8_t>(), d_toff.as<uint64_t>(), offsets, n, strict_acgt, out);
+}
+
+int pba_seqs_from_device_text(pba_ctx *ctx, const void *d_text, const void *d_offsets, uint32_t n, uint64_t total_bytes,
+                              uint32_t max_len, pba_seqs **out) {
+    (void)total_bytes; (void)max_len;
+    if (!ctx || !d_offsets || !out || (!d_text && n)) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint64_t> h_toff(n + 1);
+    HIPCHK(hipMemcpyAsync(h_toff.data(), d_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return seqs_pack(ctx, (const uint8_t *)d_text, (const uint64_t *)d_offsets, h_toff.data(), n, 0, out);
+}
+
+int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, uint32_t min_excl, uint32_t max_excl,
+                          pba_seqs **out) {
+    if (!ctx || !out || (!file && file_len)) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t total = 0;
+    const size_t kept = pba_open_binary(file, file_len, min_excl, max_excl, nullptr, 0, &total);
+    if (kept > 0x7FFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "too many records");
+    std::vector<uint64_t> recs(kept + 1);
+    pba_open_binary(file, file_len, min_excl, max_excl, recs.data(), kept, nullptr);
+    pba_seqs *s = new (std::nothrow) pba_seqs();
+    if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
+    s->ctx = ctx; s->n = (uint32_t)kept; s->max_len = 0; s->non_acgt = false; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr; s->d_planes = nullptr; s->d_poff = nullptr; s->plane_words = 0;
+    s->h_off.resize(kept + 1); s->h_len.resize(kept + 1);
+    for (size_t i = 0; i < kept; ++i) {
+        uint32_t L;
+        memcpy(&L, file + recs[i], 4);
+        if (recs[i] + 4 + ((uint64_t)L + 3) / 4 > file_len) { delete s; PBA_FAIL(PBA_E_INVALID, "truncated record"); }
+        s->h_off[i] = recs[i] + 4;      // payload follows the u32 length (dna_seq.h:119-121)
+        s->h_len[i] = L;
+        s->max_len = std::max(s->max_len, L);
+    }
+    s->h_off[kept] = file_len; s->h_len[kept] = 0;
+    // the file image goes up as it is (no re-packing); the slack after it is large enough for
+    // seed_at's byte-offset reads to stay inside the allocation and read zeros
+    const uint64_t slack = 65536;
+    s->packed_bytes = file_len;
+    hipError_t e = hipMalloc((void **)&s->d_alloc, file_len + slack + kSlack);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_alloc, 0, file_len + slack + kSlack, ctx->stream);
+    if (e == hipSuccess) s->d_packed = s->d_alloc + kSlack;
+    if (e == hipSuccess && file_len) e = hipMemcpyAsync(s->d_packed, file, file_len, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (kept + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (kept + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * (kept + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_len, s->h_len.data(), sizeof(uint32_t) * (kept + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "pba_seqs_from_records", e); }
+    const int stp = seqs_planes(ctx, s);
+    if (stp != PBA_OK) { pba_seqs_destroy(s); return stp; }
+    *out = s;
+    return PBA_OK;
+}
+
+uint32_t pba_seqs_count(const pba_seqs *s) { return s ? s->n : 0; }
+uint32_t pba_seqs_max_len(const pba_seqs *s) { return s ? s->max_len : 0; }
+uint64_t pba_seqs_packed_bytes(const pba_seqs *s) { return s ? s->packed_bytes : 0; }
+
+int pba_seqs_lengths(const pba_seqs *s, uint32_t *lengths, uint32_t cap) {
+    if (!s || !lengths) return PBA_E_INVALID;
+    for (uint32_t i = 0; i < s->n && i < cap; ++i) lengths[i] = s->h_len[i];
+    return PBA_OK;
+}
+
+int pba_seqs_get_text(pba_ctx *ctx, const pba_seqs *s, uint32_t i, char *text, size_t cap) {
+    if (!ctx || !s || !text || i >= s->n) return PBA_E_INVALID;
+    const uint32_t L = s->h_len[i];
+    if (cap <= L) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<uint8_t> pk(((size_t)L + 3) / 4 + 1);
+    if (L) HIPCHK(hipMemcpyAsync(pk.data(), s->d_packed + s->h_off[i], ((size_t)L + 3) / 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    static const char base[4] = {'A', 'C', 'G', 'T'};
+    for (uint32_t k = 0; k < L; ++k) text[k] = base[(pk[k >> 2] >> (6 - 2 * (k & 3))) & 3];
+    text[L] = 0;
+    return PBA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host API: seed index
+// ---------------------------------------------------------------------------------------------
+void pba_index_destroy(pba_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    if (ix->d_ent) (void)hipFree(ix->d_ent);
+    if (ix->d_part_off) (void)hipFree(ix->d_part_off);
+    delete ix;
+}
+
+uint64_t pba_index_entries(const pba_index *ix) { return ix ? ix->n_entries : 0; }
+uint32_t pba_index_visited(const pba_index *ix) { return ix ? ix->visited : 0; }
+
+// sort one oversize partition in global memory
+int sort_partition_global(pba_ctx *ctx, uint64_t *d_part, uint32_t n) {
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    DevBuf tmp;
+    HIPCHK(hipMalloc(&tmp.p, sizeof(uint64_t) * N));
+    HIPCHK(hipMemcpyAsync(tmp.p, d_part, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (N > n)
+        hipLaunchKernelGGL(k_fill_u64, dim3((N - n + 255) / 256), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(), n, N,
+                           ~0ull);
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1)
+            hipLaunchKernelGGL(k_bitonic_step, dim3((N / 2 + 255) / 256), dim3(256), 0, ctx->stream, tmp.as<uint64_t>(),
+                               N, k, j);
+    HIPCHK(hipMemcpyAsync(d_part, tmp.p, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+// the reference's visiting order as at most two position segments (+ what get_seedmap returns)
+struct VisitPlan {
+    ScanSeg segs[2];
+    int nseg;
+    uint32_t visited, nhead;
+    int32_t tail_top;
+};
+
+static VisitPlan visit_plan(uint32_t len, int mode) {
+    VisitPlan v;
+    v.nseg = 0; v.visited = 0; v.nhead = 0xFFFFFFFFu; v.tail_top = 0;
+    if (mode == PBA_INDEX_ALL) {                       // locator.cpp:62: for i in [0, len)
+        if (len) v.segs[v.nseg++] = ScanSeg{0, len, 0, 0};
+        v.visited = len;
+    } else {                                           // ref_seq.h:291-311, MAX_READ_LEN = 20000, N_SEQ_WORD = 16
+        const long long L = len, nmax = L - 16;
+        const long long nh = std::min(nmax, 20000ll);
+        const long long nt = std::min(L - 20000 - 16, 20000ll);
+        v.nhead = nh > 0 ? (uint32_t)nh : 0;
+        v.tail_top = (int32_t)(L - 16);
+        if (nh > 0) v.segs[v.nseg++] = ScanSeg{0, (uint32_t)nh, 0, 0};
+        if (nt > 0) v.segs[v.nseg++] = ScanSeg{(uint32_t)(L - 16 - nt + 1), (uint32_t)(L - 16 + 1), v.nhead, 1};
+        v.visited = (uint32_t)(nh + (nt < 0 ? 0 : nt));   // ref_seq.h:310 (a negative nhead is added as it is)
+    }
+    return v;
+}
+
+static uint32_t seg_grid(const ScanSeg &sg) {
+    const uint64_t chunks = ((uint64_t)sg.hi + 15) / 16 - sg.lo / 16;
+    return (uint32_t)((chunks + PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS - 1) / (PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS));
+}
+
+static int index_logp(uint64_t n) {
+    int logP = 0;
+    while (logP < PBA_IX_MAX_LOGP && (n >> logP) > 1024) ++logP;
+    return logP;
+}
+
+static pba_index *index_new(pba_ctx *ctx, uint32_t mask, uint32_t len, int mode, const VisitPlan &v) {
+    pba_index *ix = new (std::nothrow) pba_index();
+    if (!ix) return nullptr;
+    ix->ctx = ctx; ix->mask = mask; ix->seq_len = len; ix->visited = v.visited; ix->nhead = v.nhead;
+    ix->tail_top = v.tail_top; ix->mode = mode; ix->n_entries = 0; ix->d_ent = nullptr; ix->d_part_off = nullptr;
+    ix->logP = 0;
+    return ix;
+}
+
+// counts are in cnt (device, P+1 u32): turn them into offsets, allocate the entry array, let `scatter`
+// fill it (cnt then holds the cursors), sort every partition
+static int index_finish(pba_ctx *ctx, pba_index *ix, DevBuf &cnt, const std::function<void()> &scatter) {
+    const uint32_t P = 1u << ix->logP;
+    std::vector<uint32_t> h_cnt(P + 1, 0), h_off(P + 1, 0);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < P; ++p) { h_off[p] = (uint32_t)total; total += h_cnt[p]; }
+    if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "more than 2^32 index entries");
+    h_off[P] = (uint32_t)total;
+    ix->n_entries = total;
+    HIPCHK(hipMalloc((void **)&ix->d_ent, sizeof(uint64_t) * (total + 1)));
+    HIPCHK(hipMalloc((void **)&ix->d_part_off, sizeof(uint32_t) * (P + 1)));
+    HIPCHK(hipMemcpyAsync(ix->d_part_off, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cnt.p, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));   // cursors
+    if (total) {
+        tu_attrs();
+        scatter();
+        // LDS by need, not by capacity: a 2 048-entry partition takes 16 KB, so ten workgroups share a CU
+        // instead of one (k_part_sort was 0.61 ms of a 0.77 ms build at 5 Mb with the full 128 KB request)
+        uint32_t biggest = 2;
+        for (uint32_t p = 0; p < P; ++p)
+            if (h_cnt[p] <= PBA_IX_LDS_SORT_CAP) biggest = std::max(biggest, h_cnt[p]);
+        uint32_t pow2 = 2;
+        while (pow2 < biggest) pow2 <<= 1;
+        hipLaunchKernelGGL(k_part_sort, dim3(P), dim3(256), sizeof(uint64_t) * pow2, ctx->stream, ix->d_ent,
+                           ix->d_part_off);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        for (uint32_t p = 0; p < P; ++p)
+            if (h_cnt[p] > PBA_IX_LDS_SORT_CAP) {
+                int st = sort_partition_global(ctx, ix->d_ent + h_off[p], h_cnt[p]);
+                if (st != PBA_OK) return st;
+            }
+    }
+    (void)hipEventRecord(ctx->ev[1], ctx->stream);
+    (void)hipEventSynchronize(ctx->ev[1]);
+    (void)hipEventElapsedTime(&ctx->prof.index_ms, ctx->ev[0], ctx->ev[1]);
+    return PBA_OK;
+}
+
+int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode, pba_index **out) {
+    if (!ctx || !target || !out || seq >= target->n) return PBA_E_INVALID;
+    if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t len = target->h_len[seq];
+    if (len > 0x7FFFFFF0u) PBA_FAIL(PBA_E_TOOLONG, "target sequence");
+    const VisitPlan v = visit_plan(len, mode);
+    pba_index *ix = index_new(ctx, mask, len, mode, v);
+    if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
+    uint64_t npos = 0;
+    for (int s = 0; s < v.nseg; ++s) npos += v.segs[s].hi - v.segs[s].lo;
+    ix->logP = index_logp(npos);
+    const int logP = ix->logP;
+    const uint32_t P = 1u << logP;
+    const uint8_t *d_seq = target->d_packed + target->h_off[seq];
+    DevBuf cnt;
+    hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
+    if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
+    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    for (int s = 0; s < v.nseg; ++s)
+        hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+                           mask, v.segs[s], logP, cnt.as<uint32_t>());
+    int st = index_finish(ctx, ix, cnt, [&]() {
+        for (int s = 0; s < v.nseg; ++s)
+            hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq,
+                               len, mask, v.segs[s], logP, cnt.as<uint32_t>(), ix->d_ent);
+    });
+    if (st != PBA_OK) { pba_index_destroy(ix); return st; }
+    *out = ix;
+    return PBA_OK;
+}
+
+int pba_index_scan(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t mask, int mode, uint32_t part,
+                   uint32_t nparts, void *d_entries, uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !target || !d_entries || !n_out || seq >= target->n || nparts == 0 || part >= nparts) return PBA_E_INVALID;
+    if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t len = target->h_len[seq];
+    const VisitPlan v = visit_plan(len, mode);
+    // this rank's contiguous slice of the ordinal space [0, visited)
+    const uint64_t nv = v.nseg ? (uint64_t)v.segs[v.nseg - 1].ord0 + (v.segs[v.nseg - 1].hi - v.segs[v.nseg - 1].lo) : 0;
+    const uint64_t o_lo = nv * part / nparts, o_hi = nv * (part + 1) / nparts;
+    DevBuf counter;
+    HIPCHK(hipMalloc(&counter.p, 8));
+    HIPCHK(hipMemsetAsync(counter.p, 0, 8, ctx->stream));
+    const uint8_t *d_seq = target->d_packed + target->h_off[seq];
+    for (int s = 0; s < v.nseg; ++s) {
+        const ScanSeg &g = v.segs[s];
+        const uint64_t g_lo = g.ord0, g_hi = (uint64_t)g.ord0 + (g.hi - g.lo);
+        const uint64_t a = std::max(o_lo, g_lo), b = std::min(o_hi, g_hi);
+        if (a >= b) continue;
+        ScanSeg c;
+        c.descending = g.descending; c.ord0 = (uint32_t)a;
+        if (!g.descending) { c.lo = g.lo + (uint32_t)(a - g_lo); c.hi = g.lo + (uint32_t)(b - g_lo); }
+        else { c.lo = g.hi - (uint32_t)(b - g_lo); c.hi = g.hi - (uint32_t)(a - g_lo); }
+        hipLaunchKernelGGL(k_seed_emit, dim3(seg_grid(c)), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len, mask, c,
+                           (uint64_t *)d_entries, (unsigned long long)cap, counter.as<unsigned long long>());
+    }
+    HIPCHK(hipGetLastError());
+    unsigned long long h_n = 0;
+    HIPCHK(hipMemcpyAsync(&h_n, counter.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (h_n > cap) PBA_FAIL(PBA_E_INVALID, "pba_index_scan: entry buffer too small");
+    *n_out = h_n;
+    return PBA_OK;
+}
+
+int pba_index_from_entries(pba_ctx *ctx, const void *d_entries, uint64_t n, uint32_t mask, int mode, uint32_t seq_len,
+                           pba_index **out) {
+    if (!ctx || !out || (!d_entries && n)) return PBA_E_INVALID;
+    if (mode != PBA_INDEX_ALL && mode != PBA_INDEX_HEAD_TAIL) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    const VisitPlan v = visit_plan(seq_len, mode);
+    pba_index *ix = index_new(ctx, mask, seq_len, mode, v);
+    if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
+    ix->logP = index_logp(n);
+    const int logP = ix->logP;
+    const uint32_t P = 1u << logP;
+    DevBuf cnt;
+    hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
+    if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
+    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
+    const uint32_t grid = (uint32_t)((n + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS);
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    if (grid)
+        hipLaunchKernelGGL(k_ent_count, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, (const uint64_t *)d_entries, n,
+                           logP, cnt.as<uint32_t>());
+    int st = index_finish(ctx, ix, cnt, [&]() {
+        hipLaunchKernelGGL(k_ent_scatter, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, (const uint64_t *)d_entries,
+                           n, logP, cnt.as<uint32_t>(), ix->d_ent);
+    });
+    if (st != PBA_OK) { pba_index_destroy(ix); return st; }
+    *out = ix;
+    return PBA_OK;
+}
+
+int pba_index_dump(pba_ctx *ctx, const pba_index *ix, uint32_t *keys, int32_t *pos, uint64_t cap, uint64_t *n) {
+    if (!ctx || !ix || !n) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    *n = ix->n_entries;
+    if (!keys || !pos) return PBA_OK;
+    std::vector<uint64_t> ent(ix->n_entries + 1);
+    if (ix->n_entries)
+        HIPCHK(hipMemcpyAsync(ent.data(), ix->d_ent, sizeof(uint64_t) * ix->n_entries, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ent.resize(ix->n_entries);
+    std::sort(ent.begin(), ent.end());          // partitions are sorted; this only merges them by key
+    for (uint64_t i = 0; i < ent.size() && i < cap; ++i) {
+        const uint32_t ord = (uint32_t)ent[i];
+        keys[i] = (uint32_t)(ent[i] >> 32);
+        pos[i] = ord < ix->nhead ? (int32_t)ord : ix->tail_top - (int32_t)(ord - ix->nhead);
+    }
+    return PBA_OK;
+}
+
+int pba_index_find(pba_ctx *ctx, const pba_index *ix, const uint32_t *keys, uint32_t n_keys, uint64_t *hit_off,
+                   int32_t *hit_pos, uint64_t hit_cap) {
+    if (!ctx || !ix || !hit_off || (!keys && n_keys)) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    hit_off[0] = 0;
+    if (!n_keys) return PBA_OK;
+    DevBuf d_keys, d_beg, d_cnt, d_off, d_pos;
+    HIPCHK(hipMalloc(&d_keys.p, 4ull * n_keys));
+    HIPCHK(hipMalloc(&d_beg.p, 4ull * n_keys));
+    HIPCHK(hipMalloc(&d_cnt.p, 4ull * n_keys));
+    HIPCHK(hipMemcpyAsync(d_keys.p, keys, 4ull * n_keys, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_find_count, dim3((n_keys + 255) / 256), dim3(256), 0, ctx->stream, ix->dev(),
+                       d_keys.as<uint32_t>(), n_keys, d_beg.as<uint32_t>(), d_cnt.as<uint32_t>());
+    std::vector<uint32_t> cnt(n_keys);
+    HIPCHK(hipMemcpyAsync(cnt.data(), d_cnt.p, 4ull * n_keys, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = 0; q < n_keys; ++q) hit_off[q + 1] = hit_off[q] + cnt[q];
+    const uint64_t total = hit_off[n_keys];
+    if (!hit_pos || !total) return PBA_OK;
+    const uint64_t ncopy = std::min(total, hit_cap);
+    HIPCHK(hipMalloc(&d_off.p, 8ull * (n_keys + 1)));
+    HIPCHK(hipMalloc(&d_pos.p, 4ull * (ncopy + 1)));
+    HIPCHK(hipMemcpyAsync(d_off.p, hit_off, 8ull * (n_keys + 1), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_find_fill, dim3((n_keys + 255) / 256), dim3(256), 0, ctx->stream, ix->dev(), d_beg.as<uint32_t>(),
+                       d_off.as<uint64_t>(), n_keys, d_pos.as<int32_t>(), ncopy);
+    HIPCHK(hipMemcpyAsync(hit_pos, d_pos.p, 4ull * ncopy, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    return PBA_OK;
+}
+
+}  // extern "C"

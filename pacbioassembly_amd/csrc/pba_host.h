@@ -1,0 +1,173 @@
+// pba_host.h -- host-side objects and helpers shared by the translation units of libpba.so (pba_core.hip: context,
+// sequence sets, seed index; pba_align.hip: explicit pairs and edit scripts; pba_drivers.hip: the reference's ordered
+// first-success loops; pba_overlap.hip: all-vs-all; pba_cons.hip: consensus voting).  Internal: nothing here is part of
+// the C ABI (include/pba.h).
+#ifndef PBA_HOST_H
+#define PBA_HOST_H
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <new>
+#include <vector>
+
+#include "align_common.h"
+#include "consensus.h"
+#include "dev_common.h"
+#include "pba.h"
+#include "seed_index.h"
+
+#define PBA_INTERNAL __attribute__((visibility("hidden")))
+// a kernel that takes more than the default 64 KB of dynamic LDS; every translation unit does this once for the kernels
+// it launches (tu_attrs() in each .hip; one process drives one GPU)
+#define PBA_BIG_LDS(kernel) (void)hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+
+// ---------------------------------------------------------------------------------------------
+// host-side objects
+// ---------------------------------------------------------------------------------------------
+struct pba_ctx {
+    int device;
+    hipStream_t own_stream, stream;
+    hipDeviceProp_t prop;
+    hipEvent_t ev[6];        // index begin/end, align begin/end, redo begin/end
+    uint32_t *d_queue;       // work-queue counters of the persistent aligning kernels (one per launch in flight)
+    void *d_scratch;         // parent-bit scratch of the trace / vote kernels, kept between calls (tens of GB: mapping
+    size_t scratch_bytes;    // it anew on every call cost seconds); grown on demand, freed with the ctx
+    pba_profile prof;
+    char err[512];
+};
+
+static const size_t kPlaneSlack = 64;           // zero words before the first and after the last sequence of a bit plane
+struct pba_seqs {
+    pba_ctx *ctx;
+    uint32_t n, max_len;
+    uint64_t packed_bytes;   // packed payload resident in HBM (incl. alignment padding)
+    bool non_acgt;           // some byte outside ACGT was packed as code 3 (C2I): the packed DP would match it against T
+    uint8_t *d_alloc;        // allocation; d_packed = d_alloc + kSlack
+    uint8_t *d_packed;
+    uint64_t *d_off;
+    uint32_t *d_len;
+    uint32_t *d_planes;      // allocation of the two bit planes, interleaved word by word, kPlaneSlack zero word pairs around them
+    uint64_t *d_poff;        // word offset of every sequence inside a plane
+    uint64_t plane_words;    // words of one plane incl. its slack
+    std::vector<uint64_t> h_off;
+    std::vector<uint32_t> h_len;
+    SeqSetDev dev() const { return SeqSetDev{d_packed, d_off, d_len, d_planes + 2 * kPlaneSlack, d_poff}; }
+};
+
+struct pba_index {
+    pba_ctx *ctx;
+    uint32_t mask, seq_len, visited, nhead;
+    int32_t tail_top;
+    int mode, logP;
+    uint64_t n_entries;
+    uint64_t *d_ent;
+    uint32_t *d_part_off;
+    IndexDev dev() const { return IndexDev{d_ent, d_part_off, logP, mask, nhead, tail_top}; }
+};
+
+static inline int ctx_fail(pba_ctx *ctx, int st, const char *what, hipError_t e) {
+    if (ctx)
+        snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, e == hipSuccess ? pba_strerror(st) : hipGetErrorString(e));
+    return st;
+}
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t e__ = (call);                                            \
+        if (e__ != hipSuccess) return ctx_fail(ctx, PBA_E_HIP, #call, e__); \
+    } while (0)
+#define PBA_FAIL(st, what) return ctx_fail(ctx, (st), (what), hipSuccess)
+
+// engine limits
+static const int kMaxSeqLen = 65000;            // u16 DP costs: D(i,j) <= max(i,j) < 65535
+static const int kRowSweepLdsCap = 96 * 1024;   // LDS bytes one wavefront may take for its band row
+static const size_t kSlack = 1024;              // readable bytes before the first and after the last packed byte
+                                                // (the bit-vector kernel streams a few hundred bases past an accessor)
+
+// RAII for temporaries so early returns do not leak device memory
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// host API: alignment
+// ---------------------------------------------------------------------------------------------
+static inline int max_dst_of(int la, int lb, double R) {      // seq_aligner.h:94-102
+    return 1 + (int)((lb >= la ? la : lb) * R);
+}
+
+// Launch plan for a batch whose widest band is max_dst_max.
+struct Plan {
+    AlignCfg cfg;
+    size_t lds;
+    int nb1;     // first launch: 0 = row sweep, else bit-vector array with nb1 blocks per lane (narrow band)
+    int nb2;     // second launch (uncertified pairs only): bit-vector array at the reference band
+};
+
+static inline int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kernel, int max_dst_max, Plan *pl) {
+    if (!(R > 0.0) || !(R < 1.0)) PBA_FAIL(PBA_E_INVALID, "R must be in (0,1)");
+    if (kernel != PBA_KERNEL_AUTO && kernel != PBA_KERNEL_ROWSWEEP && kernel != PBA_KERNEL_BITVEC)
+        PBA_FAIL(PBA_E_INVALID, "unknown kernel");
+    const bool bv = kernel != PBA_KERNEL_ROWSWEEP && bitvec_supports(max_dst_max);
+    if (kernel == PBA_KERNEL_BITVEC && !bv) PBA_FAIL(PBA_E_TOOLONG, "band too wide for the bit-vector kernel");
+    // the bit-vector kernel needs LDS only for its m <= 10 corner (a 23-cell row at most); the row sweep
+    // needs the whole band row
+    const long long W = bv ? 127 : 2ll * max_dst_max + 1;
+    const long long bytes = ((W * 2 + 15) / 16) * 16;
+    if (bytes > kRowSweepLdsCap) PBA_FAIL(PBA_E_TOOLONG, "band row does not fit the per-wavefront LDS budget");
+    pl->cfg.R = R; pl->cfg.maxn = maxn; pl->cfg.maxm = maxm; pl->cfg.full_band = 0;
+    pl->cfg.row_cap = (int)(bytes / 2);
+    pl->lds = (size_t)bytes;
+    pl->nb1 = bv ? bv_nb_for_span(bv_first_wl(max_dst_max) + bv_first_w(max_dst_max)) : 0;
+    pl->nb2 = bv ? bv_nb_for_span(bv_full_wl(max_dst_max) + max_dst_max) : 0;
+    return PBA_OK;
+}
+
+// Workgroups for a persistent launch: enough to fill every CU (up to 8 waves per SIMD, as many as the LDS
+// allows), never more than there are work items.  Any residency works: the queue needs no co-residency.
+static inline uint32_t persistent_grid(const pba_ctx *ctx, uint32_t n_items, int waves_per_wg, size_t lds_per_wave) {
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    uint32_t wg_per_cu = 32u / (uint32_t)waves_per_wg;
+    const size_t lds_wg = lds_per_wave * (size_t)waves_per_wg;
+    if (lds_wg) wg_per_cu = std::min<uint32_t>(wg_per_cu, (uint32_t)std::max<size_t>(1, (160 * 1024) / lds_wg));
+    const uint32_t need = (n_items + (uint32_t)waves_per_wg - 1) / (uint32_t)waves_per_wg;
+    return std::max(1u, std::min(need, cus * wg_per_cu));
+}
+
+static inline void prof_finish(pba_ctx *ctx) {      // all launches of the call have completed (stream synchronised)
+    (void)hipEventElapsedTime(&ctx->prof.align_ms, ctx->ev[2], ctx->ev[3]);
+    if (ctx->prof.n_redo) (void)hipEventElapsedTime(&ctx->prof.align_redo_ms, ctx->ev[4], ctx->ev[5]);
+}
+
+static inline bool pair_ok(const pba_seqs *S, uint32_t seq, int pos, int len, bool backward) {
+    if (seq >= S->n || len < 0 || len > kMaxSeqLen || pos < 0) return false;
+    const long long L = S->h_len[seq];
+    if (len == 0) return pos <= L;
+    return backward ? (pos < L && pos - (len - 1) >= 0) : ((long long)pos + len <= L);
+}
+
+// ---- internal entry points that cross translation units
+extern "C" {
+// sort one oversize partition / candidate piece in global memory (pba_core.hip)
+PBA_INTERNAL int sort_partition_global(pba_ctx *ctx, uint64_t *d_part, uint32_t n);
+// edit scripts of a batch, or their votes (pba_align.hip)
+struct pba_cons;
+PBA_INTERNAL int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pair *pairs, size_t n, double R,
+                             int maxn, int maxm, int kernel, pba_result *out, uint8_t *ops, const uint64_t *ops_off,
+                             int32_t *nedit, const pba_cons *vote, int overlap_min);
+// the vote boxes a batch of walks votes into (pba_cons.hip)
+PBA_INTERNAL int cons_vote_view(const pba_cons *c, ConsDev *dev, int *beg, int *pre, int *post);
+// one locked round over a subset of the reads (pba_drivers.hip)
+PBA_INTERNAL int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, uint32_t ref_seq, const pba_seqs *reads,
+                                     double R, int max_trial, int overlap_min, int buggy_seed_at, int kernel,
+                                     const uint32_t *subset, uint32_t n_subset, pba_ss_row *rows, int ref_org = 0, int maxn = 0,
+                                     int maxm = 0, uint8_t *touch = nullptr);
+}  // extern "C"
+
+#endif

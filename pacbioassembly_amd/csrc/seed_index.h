@@ -104,7 +104,7 @@ __device__ __forceinline__ void dir_find(const KeyDir &d, const uint64_t *ent, u
     beg = d.dir[dir_compress(d, key)];
     cnt = beg == PBA_DIR_EMPTY ? 0u : ix_run_end(ent, beg, d.n_entries, key) - beg;
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_dir_build(const uint64_t *ent, uint32_t n, KeyDir d, uint32_t *dir) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t chunk_key(uint64_t be, uint32_t k, uint32_t 
 }
 
 // pass 1: partition sizes
-__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int logP, uint32_t *part_cnt) {
     __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
     const uint32_t P = 1u << logP;
@@ -156,7 +156,7 @@ k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int lo
 }
 
 // pass 2: scatter entries into their partitions (order inside a partition is fixed by the sort)
-__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int logP, uint32_t *part_cursor,
                uint64_t *ent) {
     __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
@@ -204,7 +204,7 @@ k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int 
 }
 
 // ---- multi-GPU exchange form: a rank scans its slice of the visiting order into a flat entry list ...
-__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_seed_emit(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, uint64_t *out, unsigned long long cap,
             unsigned long long *counter) {
     __shared__ uint32_t wg_count, wg_base_lo, wg_base_hi;
@@ -250,7 +250,7 @@ k_seed_emit(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, uint64_
 }
 
 // ... and every rank builds the partitions from the gathered list (all-ones entries are padding)
-__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_ent_count(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cnt) {
     __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
     const uint32_t P = 1u << logP;
@@ -268,7 +268,7 @@ k_ent_count(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cnt) {
         if (hist[p]) atomicAdd(&part_cnt[p], hist[p]);
 }
 
-__global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_ent_scatter(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cursor, uint64_t *ent) {
     __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
     __shared__ uint32_t base[1 << PBA_IX_MAX_LOGP];
@@ -300,7 +300,7 @@ k_ent_scatter(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cursor, u
 }
 
 // pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
-__global__ void __launch_bounds__(1024) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
+static __global__ void __launch_bounds__(1024) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
     extern __shared__ __align__(16) uint64_t s_ent[];
     const uint32_t lo = part_off[blockIdx.x], n = part_off[blockIdx.x + 1] - lo;
     if (n < 2 || n > PBA_IX_LDS_SORT_CAP) return;     // oversize partitions take the global path
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(1024) k_part_sort(uint64_t *ent, const uint32_
 }
 
 // global-memory bitonic step for partitions too large for LDS (low-complexity targets)
-__global__ void k_bitonic_step(uint64_t *buf, uint32_t N, uint32_t k, uint32_t j) {
+static __global__ void k_bitonic_step(uint64_t *buf, uint32_t N, uint32_t k, uint32_t j) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (N >> 1)) return;
     const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
@@ -333,20 +333,20 @@ __global__ void k_bitonic_step(uint64_t *buf, uint32_t N, uint32_t k, uint32_t j
     const bool up = (i & k) == 0;
     if ((x > y) == up) { buf[i] = y; buf[l] = x; }
 }
-__global__ void k_fill_u64(uint64_t *buf, uint32_t from, uint32_t to, uint64_t v) {
+static __global__ void k_fill_u64(uint64_t *buf, uint32_t from, uint32_t to, uint64_t v) {
     const uint32_t i = from + blockIdx.x * blockDim.x + threadIdx.x;
     if (i < to) buf[i] = v;
 }
 
 // batch find, two launches: counts, then positions in list order
-__global__ void k_find_count(IndexDev ix, const uint32_t *keys, uint32_t n, uint32_t *beg, uint32_t *cnt) {
+static __global__ void k_find_count(IndexDev ix, const uint32_t *keys, uint32_t n, uint32_t *beg, uint32_t *cnt) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     uint32_t b = 0, c = 0;
     if (keys[q]) ix_find(ix, keys[q], b, c);
     beg[q] = b; cnt[q] = c;
 }
-__global__ void k_find_fill(IndexDev ix, const uint32_t *beg, const uint64_t *hit_off, uint32_t n, int32_t *hit_pos,
+static __global__ void k_find_fill(IndexDev ix, const uint32_t *beg, const uint64_t *hit_off, uint32_t n, int32_t *hit_pos,
                             uint64_t cap) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
