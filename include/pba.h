@@ -75,6 +75,10 @@ void pba_synth_genome(uint64_t seed, char *out, size_t n);
  * (no separators); starts (nullable) receives each read's genome start. */
 int pba_synth_reads(uint64_t seed, const char *genome, size_t L, uint32_t n_reads, uint32_t read_len,
                     double p_ins, double p_del, double p_sub, char *out, uint32_t *starts, int nthreads);
+/* reads [r_lo, r_hi) of the same set (read r is a function of (seed, r) only): what one rank of a multi-GPU run generates.
+ * out holds (r_hi - r_lo) * read_len chars, starts (nullable) r_hi - r_lo slots. */
+int pba_synth_reads_range(uint64_t seed, const char *genome, size_t L, uint32_t r_lo, uint32_t r_hi, uint32_t read_len,
+                          double p_ins, double p_del, double p_sub, char *out, uint32_t *starts, int nthreads);
 
 /* ------------------------------------------------------------------------ */
 /* Context                                                                  */
@@ -126,6 +130,16 @@ int pba_seqs_from_device_text(pba_ctx *ctx, const void *d_text, const void *d_of
  * (spaced_seed.cpp:330-342); payloads are uploaded as they are, no re-packing */
 int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, uint32_t min_excl,
                           uint32_t max_excl, pba_seqs **out);
+/* Multi-GPU exchange of packed reads (every rank packs its own shard, the shards are all-gathered over RCCL):
+ * pba_seqs_export copies the set's packed arena (pba_seqs_packed_bytes bytes) into the DEVICE buffer d_dst and returns the
+ * byte offset of every sequence's first packed byte in it (offsets: n host slots); pba_seqs_from_device_packed builds a
+ * set from such bytes resident on the device -- the gathered buffer, offsets[i] = where sequence i starts in it (rank
+ * base + exported offset), lengths in bases -- without re-packing (one device copy; the bit planes are rebuilt).
+ * non_acgt: whether any contributing set was built with strict_acgt == 0 and met a byte outside ACGT. */
+int pba_seqs_export(pba_ctx *ctx, const pba_seqs *s, void *d_dst, uint64_t cap, uint64_t *offsets);
+int pba_seqs_from_device_packed(pba_ctx *ctx, const void *d_packed, uint64_t n_bytes, const uint64_t *offsets,
+                                const uint32_t *lengths, uint32_t n, int non_acgt, pba_seqs **out);
+int pba_seqs_non_acgt(const pba_seqs *s);
 void pba_seqs_destroy(pba_seqs *s);
 uint32_t pba_seqs_count(const pba_seqs *s);
 uint32_t pba_seqs_max_len(const pba_seqs *s);
@@ -368,7 +382,20 @@ typedef struct {
     uint64_t n_redo;               /* (target, query) runs resumed at the reference band (narrow window not certified) */
     float scan_ms, sort_ms, walk_ms;
     uint32_t wide_first;           /* 1: a sample showed the narrow window rarely certifies, the rest went straight to the reference band */
+    float table_ms;                /* build of the probe table this call scanned against (once per table, not per call) */
+    uint32_t n_big_targets;        /* targets whose candidates outgrew one LDS sort and were cut into pieces of consecutive queries */
 } pba_overlap_stats;
+
+/* Limits of the all-vs-all entry points (explicit PBA_E_TOOLONG beyond them, never a wrapped count):
+ *   reads                      < PBA_OVL_MAX_READS       (a candidate packs the query id next to 23 bits of probe and ordinal)
+ *   reads * 2 * max_trial      < PBA_OVL_MAX_PROBES      (a probe id is 32 bits)
+ *   candidates of ONE call     < PBA_OVL_MAX_CANDIDATES  (offsets into the candidate array are 32 bits: go through the targets
+ *                                                         in ranges [t_lo, t_hi) against one probe table -- BASELINE config 5,
+ *                                                         10 M reads, takes ~4 000 targets per call)
+ *   max_trial                  in [1, 63], read length <= 65 000 */
+#define PBA_OVL_MAX_READS (1u << 24)
+#define PBA_OVL_MAX_PROBES (1ull << 32)
+#define PBA_OVL_MAX_CANDIDATES 0xFFFFFFF0ull
 
 /* out: caller-allocated, cap entries; *n_out = overlaps found (may exceed cap: then only cap are written).
  * Results are sorted by (target, query).  Targets shard across GPUs through [t_lo, t_hi). */
@@ -384,6 +411,17 @@ int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint3
 int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, const void *d_probe_entries,
                            uint64_t n_probe_slots, uint32_t mask, double R, int max_trial, int overlap_min, int kernel,
                            pba_overlap *out, uint64_t cap, uint64_t *n_out, pba_overlap_stats *stats);
+/* The same in two steps, for read sets that go through the targets in many ranges (or many ranks' worth of them): the
+ * probe table -- what hash_table is to one reference (common.h:54), for the probes of every read: bucket offsets by key,
+ * the probe ids bucket by bucket, one presence bit per key -- is built ONCE from the (gathered) DEVICE entry list and
+ * every pba_overlap_all_table call scans its target range against it. */
+typedef struct pba_probe_table pba_probe_table;
+int pba_probe_table_create(pba_ctx *ctx, const void *d_probe_entries, uint64_t n_probe_slots, uint32_t mask, int max_trial,
+                           pba_probe_table **out);
+void pba_probe_table_destroy(pba_probe_table *t);
+uint64_t pba_probe_table_entries(const pba_probe_table *t);
+int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, const pba_probe_table *tab, double R,
+                          int overlap_min, int kernel, pba_overlap *out, uint64_t cap, uint64_t *n_out, pba_overlap_stats *stats);
 
 const char *pba_strerror(int status);
 

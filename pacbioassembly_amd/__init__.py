@@ -5,6 +5,6 @@ include/pba.h) plus the C++ compat headers in include/compat/.  `engine` wraps t
 bench.py.  There is no CPU implementation in this package.
 """
 from . import _lib, engine  # noqa: F401
-from .engine import Consensus, Context, PbaError, SeedIndex, SeqSet  # noqa: F401
+from .engine import Consensus, Context, PbaError, ProbeTable, SeedIndex, SeqSet  # noqa: F401
 
-__all__ = ["Consensus", "Context", "PbaError", "SeedIndex", "SeqSet", "engine"]
+__all__ = ["Consensus", "Context", "PbaError", "ProbeTable", "SeedIndex", "SeqSet", "engine"]

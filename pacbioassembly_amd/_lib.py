@@ -35,7 +35,7 @@ class PbaLocStats(C.Structure):
 class PbaOverlapStats(C.Structure):
     _fields_ = [("n_probe_entries", C.c_uint64), ("n_candidates", C.c_uint64), ("n_pairs", C.c_uint64),
                 ("n_overlaps", C.c_uint64), ("n_redo", C.c_uint64), ("scan_ms", C.c_float), ("sort_ms", C.c_float),
-                ("walk_ms", C.c_float), ("wide_first", C.c_uint32)]
+                ("walk_ms", C.c_float), ("wide_first", C.c_uint32), ("table_ms", C.c_float), ("n_big_targets", C.c_uint32)]
 
 
 class PbaProfile(C.Structure):
@@ -63,6 +63,8 @@ SYMBOLS = {
     "pba_synth_genome": (None, [C.c_uint64, _P, C.c_size_t]),
     "pba_synth_reads": (C.c_int, [C.c_uint64, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
                                   C.c_double, _P, _P, C.c_int]),
+    "pba_synth_reads_range": (C.c_int, [C.c_uint64, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                        C.c_double, _P, _P, C.c_int]),
     "pba_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "pba_ctx_destroy": (None, [_P]),
     "pba_ctx_error": (C.c_char_p, [_P]),
@@ -74,6 +76,9 @@ SYMBOLS = {
     "pba_seqs_from_text": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
     "pba_seqs_from_device_text": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "pba_seqs_from_records": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "pba_seqs_export": (C.c_int, [_P, _P, _P, C.c_uint64, _P]),
+    "pba_seqs_from_device_packed": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "pba_seqs_non_acgt": (C.c_int, [_P]),
     "pba_seqs_destroy": (None, [_P]),
     "pba_seqs_count": (C.c_uint32, [_P]),
     "pba_seqs_max_len": (C.c_uint32, [_P]),
@@ -104,6 +109,11 @@ SYMBOLS = {
     "pba_overlap_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pba_overlap_all_probes": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int,
                                          C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
+    "pba_probe_table_create": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "pba_probe_table_destroy": (None, [_P]),
+    "pba_probe_table_entries": (C.c_uint64, [_P]),
+    "pba_overlap_all_table": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, _P, C.c_uint64,
+                                        C.POINTER(C.c_uint64), _P]),
     "pba_cons_create": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "pba_cons_destroy": (None, [_P]),
     "pba_cons_extent": (C.c_int, [_P, _P]),

@@ -7,12 +7,13 @@
 // Inverted form: the PROBES are indexed (2*max_trial keys per read: small, and the object a
 // multi-GPU run all-gathers), the targets' positions are scanned against that table:
 //   k_probe_emit : one probe entry (key << 32 | probe id) per (query, j, direction), key 0 dropped
-//   (partition + sort of the entries: the seed-index builder, seed_index.h)
-//   k_ovl_scan   : one workgroup per target; every indexed position of the target in get_seedmap order looks
-//                  its key up and emits one candidate per matching probe of another read,
-//                  candidate = query << 23 | (2j + backward) << 16 | ordinal   (count pass, then fill pass)
-//   (per-target sort of the candidates: k_part_sort; 64-bit order = query, then j, forward before backward,
-//    then the seedmap's list order -- exactly the order spaced_seed tries them in)
+//   k_pt_*       : the entries into a direct-address probe table (bucket offsets + entries + one presence bit per key)
+//   k_ovl_count  : one workgroup per target, 16 positions per thread from one 8-byte load: the size of its candidate slice
+//   k_ovl_fill   : the same walk plus the entries: one candidate per matching probe of another read,
+//                  candidate = query << 23 | (2j + backward) << 16 | ordinal
+//   (per-target sort of the candidates in LDS; 64-bit order = query, then j, forward before backward, then the
+//    seedmap's list order -- exactly the order spaced_seed tries them in; big targets are cut into pieces of
+//    consecutive queries first: k_ovl_split, k_piece_sort)
 //   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query;
 //                  (target, query) runs whose narrow-window verdict is not certified are parked and resumed by a
 //                  second launch at the reference band
@@ -60,68 +61,340 @@ struct HeadTail {
     __device__ __forceinline__ int pos_of(int ord) const { return ord < nhead ? ord : tail_top - (ord - nhead); }
 };
 
-// Presence filter of the probe table: one bit per hashed key (2^26 bits = 8 MB, L2 / MALL resident).  Only ~1 in 13
-// positions of a target carries a key some probe has (2*max_trial probes per read against 4^12 keys), so one bit
-// load spares the scan most of its dependent binary searches.
-#define PBA_OVL_PRES_LOG 26
-__device__ __forceinline__ uint32_t ovl_pres_slot(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - PBA_OVL_PRES_LOG); }
-static __global__ void __launch_bounds__(256)
-k_ovl_presence(const uint64_t *ent, uint64_t n, uint32_t *bits) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t h = ovl_pres_slot((uint32_t)(ent[i] >> 32));
-    atomicOr(bits + (h >> 5), 1u << (h & 31));
+// ---------------------------------------------------------------------------------------------------------------
+// The probe table: a direct-address CSR over the probe keys ("LDS-staged hash buckets" of the north star, sized for HBM:
+// the table of a million reads is 64 MB of bucket offsets + 256 MB of entries and stays resident).
+//   bucket(key) = the key's care bits gathered into one number when the mask has <= PBA_PT_MAX_BITS of them (every key
+//                 its own bucket: a lookup is ONE load of two adjacent offsets, no search, no key compare), else a
+//                 multiplicative hash into 2^PBA_PT_MAX_BITS buckets (HASHED: the entry's key is kept and compared)
+//   start[b] .. start[b+1] : the bucket's entries in pid[] (and pkey[] when HASHED)
+//   pid[i]   = query << 7 | (2j + backward)
+//   presence = one bit per bucket (2 MB for the weight-12 masks of seeds.txt: resident in every XCD's L2), consulted
+//              first -- with 20 k reads 12 of 13 positions stop there, with a million reads none do
+#define PBA_PT_MAX_BITS 26
+struct ProbeTab {
+    uint32_t *start, *pid, *pkey, *presence;
+    uint32_t mask, mv[5];
+    int bits;
+};
+template <bool HASHED>
+__device__ __forceinline__ uint32_t pt_bucket(const ProbeTab &T, uint32_t key) {
+    if (HASHED) return (key * 0x9E3779B1u) >> (32 - T.bits);
+    uint32_t x = key;                                   // compress(key, mask): Hacker's Delight 7-4, move masks from the host
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t t = x & T.mv[i];
+        x = (x ^ t) | (t >> (1 << i));
+    }
+    return x;
 }
 
-// A target's candidates are kept in PBA_OVL_SUB buckets of consecutive queries (bucket = umulhi(q, 2^32 * SUB / n_reads),
-// monotone in q, so the buckets in order are the list in query order): each bucket is counted, filled and sorted on its own, which keeps
-// every sorted piece inside the LDS sort even when a target has far more than 16 384 candidates (57 000 at a million
-// reads).  `shift` merges 2^shift neighbouring buckets (the host picks the coarsest split whose pieces still fit).
-// FILL = false: cnt[(t - t_lo) * SUB + bucket] = candidates.  FILL = true: piece p = bucket >> shift of target t is written
-// from cursor[(t - t_lo) * (SUB >> shift) + p] on.
-#define PBA_OVL_SUB 64
-template <bool FILL>
+// entries (key << 32 | probe id; all-ones = padding of an all-gathered buffer) -> bucket sizes at start[b + 1], presence bits
+template <bool HASHED>
 static __global__ void __launch_bounds__(256)
-k_ovl_scan(IndexDev probes, KeyDir kd, const uint32_t *presence, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t t2,
-           uint32_t sub_mul, int shift, uint32_t *cnt_or_cursor, uint64_t *cand) {
-    const uint32_t tl = blockIdx.x;
-    if (tl >= n_targets) return;
-    // one workgroup owns a target, so its buckets' counters / write cursors live in LDS (a global atomic per candidate on
-    // per-bucket addresses cannot be folded into one per wavefront and was the slowest part of the scan)
-    __shared__ uint32_t sub[PBA_OVL_SUB];
-    if (threadIdx.x < PBA_OVL_SUB)
-        sub[threadIdx.x] = FILL ? (threadIdx.x < (PBA_OVL_SUB >> shift) ? cnt_or_cursor[tl * (PBA_OVL_SUB >> shift) + threadIdx.x] : 0u) : 0u;
+k_pt_count(const uint64_t *in, uint64_t n, ProbeTab T) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t e = in[i];
+    if (e == ~0ull) return;
+    const uint32_t b = pt_bucket<HASHED>(T, (uint32_t)(e >> 32));
+    atomicAdd(T.start + b + 1, 1u);
+    atomicOr(T.presence + (b >> 5), 1u << (b & 31));
+}
+// ... and, once start[] has been scanned, the entries into their buckets (cursor = a copy of start)
+template <bool HASHED>
+static __global__ void __launch_bounds__(256)
+k_pt_fill(const uint64_t *in, uint64_t n, ProbeTab T, uint32_t *cursor, uint32_t t2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t e = in[i];
+    if (e == ~0ull) return;
+    const uint32_t key = (uint32_t)(e >> 32), gid = (uint32_t)e;
+    const uint32_t slot = atomicAdd(cursor + pt_bucket<HASHED>(T, key), 1u);
+    T.pid[slot] = (gid / t2) << PBA_OVL_JD_BITS | (gid % t2);
+    if (HASHED) T.pkey[slot] = key;
+}
+
+// In-place inclusive scan of a[0 .. n) in three launches: tiles of PBA_SCAN_TILE per workgroup, the tile sums by one
+// workgroup, the carry-in added back.  (2^24 - 2^26 bucket counters, once per probe table.)
+#define PBA_SCAN_TILE 2048
+static __global__ void __launch_bounds__(256)
+k_scan_tiles(uint32_t *a, uint64_t n, uint32_t *tile_sum) {
+    __shared__ uint32_t wsum[4];
+    const uint64_t base = (uint64_t)blockIdx.x * PBA_SCAN_TILE + (uint64_t)threadIdx.x * 8;
+    uint32_t v[8], run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? a[base + k] : 0u; run += v[k]; v[k] = run; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = run;                                  // inclusive scan of the per-thread sums across the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    const uint32_t t = t_lo + tl;
-    const int len = (int)Rd.len[t];
-    const uint8_t *seq = Rd.packed + Rd.off[t];
-    const HeadTail ht(len);
-    for (int ord = (int)threadIdx.x; ord < ht.visited; ord += (int)blockDim.x) {
-        const int pos = ht.pos_of(ord);
-        const uint32_t key = window_key(seq, (uint32_t)pos, (uint32_t)len) & probes.mask;
-        if (!key) continue;                                             // ref_seq.h:300,307
-        const uint32_t h = ovl_pres_slot(key);
-        if (!((presence[h >> 5] >> (h & 31)) & 1u)) continue;           // no probe has this key
-        uint32_t beg, n;
-        if (kd.dir) dir_find(kd, probes.ent, key, beg, n);
-        else ix_find(probes, key, beg, n);
-        for (uint32_t h = 0; h < n; ++h) {
-            const uint32_t pid = (uint32_t)probes.ent[beg + h];
-            const uint32_t q = pid / t2;
-            if (q == t) continue;
-            const uint32_t b = min((uint32_t)PBA_OVL_SUB - 1, __umulhi(q, sub_mul));   // ~ q * SUB / n_reads, monotone in q
-            if (FILL) {
-                const uint32_t slot = atomicAdd(&sub[b >> shift], 1u);
-                cand[slot] = (uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pid % t2) << PBA_OVL_ORD_BITS | (uint32_t)ord;
-            } else {
-                atomicAdd(&sub[b], 1u);
-            }
+    uint32_t carry = inc - run;
+    for (int k = 0; k < w; ++k) carry += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] = v[k] + carry;
+    if (threadIdx.x == 255) tile_sum[blockIdx.x] = carry + run;
+}
+static __global__ void __launch_bounds__(1024)
+k_scan_sums(uint32_t *tile_sum, uint32_t n_tiles) {      // one workgroup, exclusive scan in place
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_tiles; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t x = i < n_tiles ? tile_sum[i] : 0u;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t c = carry_s;
+        for (int k = 0; k < w; ++k) c += wsum[k];
+        if (i < n_tiles) tile_sum[i] = c + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = c + inc;
+        __syncthreads();
+    }
+}
+static __global__ void __launch_bounds__(256)
+k_scan_add(uint32_t *a, uint64_t n, const uint32_t *tile_pre) {
+    const uint32_t c = tile_pre[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * PBA_SCAN_TILE + (uint64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] += c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scan: one workgroup per target, every thread takes 16 consecutive positions from ONE 8-byte load of packed bases
+// (0.25 B per position, the algorithmic read) and looks their keys up with all 16 loads of a stage in flight at once --
+// the scan is bound by the rate at which the memory system serves random lines, not by arithmetic.
+//   k_ovl_count : candidates a target will produce at most (probe entries in the buckets its keys reach) -> its slice of
+//                 the candidate array.  One presence bit and, behind it, one offset pair per position; no entry is read.
+//   k_ovl_fill  : the same walk plus the entries: candidate = query << 23 | (2j + backward) << 16 | ordinal for every
+//                 entry of another read (and, HASHED, of the same key); the target's own probes and foreign keys leave
+//                 all-ones slots, which sort to the end of the slice.  valid[tl] = real candidates.
+// Positions that found entries ("runs") are compacted into LDS per wavefront, then taken 64 runs at a time, one run per
+// lane: the 16-positions-per-thread walk stays convergent and the emission is balanced whatever the hit density
+// (0.08 per position at 20 k reads, 3.8 at a million).
+#define PBA_OVL_PPT 16                                         // positions per thread and step
+#define PBA_OVL_WAVES 4                                        // wavefronts per workgroup
+#define PBA_OVL_RUNS (PBA_WAVE * PBA_OVL_PPT)                  // runs a wavefront can meet in one step
+
+struct TargetWalk {          // visiting order of ref_seq::get_seedmap as a function of the position
+    int nhead, tail_lo, tail_top, nchunks;
+    __device__ __forceinline__ TargetWalk(int len) {
+        const HeadTail ht(len);
+        nhead = ht.nhead; tail_top = ht.tail_top;
+        tail_lo = tail_top - (ht.visited - ht.nhead) + 1;
+        nchunks = ht.visited > 0 ? (tail_top >> 4) + 1 : 0;  // positions 0 .. len - 16
+    }
+    __device__ __forceinline__ int ord_of(int pos) const {   // -1: not visited (ref_seq.h:297-308)
+        return pos < nhead ? pos : (pos >= tail_lo && pos <= tail_top ? nhead + (tail_top - pos) : -1);
+    }
+};
+
+template <bool HASHED>
+static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
+k_ovl_count(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_t *slice) {
+    __shared__ uint32_t wsum[PBA_OVL_WAVES];
+    const uint32_t tl = blockIdx.x;
+    const int len = (int)Rd.len[t_lo + tl];
+    const uint8_t *seq = Rd.packed + Rd.off[t_lo + tl];
+    const TargetWalk tw(len);
+    uint32_t sum = 0;
+    for (int c = (int)threadIdx.x; c < tw.nchunks; c += PBA_WAVE * PBA_OVL_WAVES) {
+        const uint64_t be = chunk_bits(seq, (uint32_t)c);
+        uint32_t b[PBA_OVL_PPT], pw[PBA_OVL_PPT];
+#pragma unroll
+        for (int k = 0; k < PBA_OVL_PPT; ++k) {
+            const uint32_t key = __builtin_bswap32((uint32_t)((be << (2 * k)) >> 32)) & T.mask;
+            const bool ok = key != 0u && tw.ord_of(16 * c + k) >= 0;          // ref_seq.h:300,307
+            b[k] = ok ? pt_bucket<HASHED>(T, key) : 0xFFFFFFFFu;
+            pw[k] = T.presence[ok ? b[k] >> 5 : 0u];
+        }
+#pragma unroll
+        for (int k = 0; k < PBA_OVL_PPT; ++k) {
+            const bool hit = b[k] != 0xFFFFFFFFu && ((pw[k] >> (b[k] & 31)) & 1u);
+            const uint32_t *sp = T.start + (hit ? b[k] : 0u);
+            const uint32_t s0 = sp[0], s1 = sp[1];
+            sum += hit ? s1 - s0 : 0u;
         }
     }
-    if (!FILL) {
-        __syncthreads();
-        if (threadIdx.x < PBA_OVL_SUB) cnt_or_cursor[tl * PBA_OVL_SUB + threadIdx.x] = sub[threadIdx.x];
+#pragma unroll
+    for (int d = 1; d < PBA_WAVE; d <<= 1) sum += __shfl_xor(sum, d, PBA_WAVE);
+    if ((threadIdx.x & (PBA_WAVE - 1)) == 0) wsum[threadIdx.x / PBA_WAVE] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < PBA_OVL_WAVES; ++w) s += wsum[w];
+        slice[tl] = s;
     }
+}
+
+template <bool HASHED>
+static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
+k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, uint64_t *cand, uint32_t *valid) {
+    __shared__ uint32_t r_s0[PBA_OVL_WAVES][PBA_OVL_RUNS];         // first entry of the run
+    __shared__ uint32_t r_rel[PBA_OVL_WAVES][PBA_OVL_RUNS + 1];    // its first slot, relative to the step's reservation
+    __shared__ uint16_t r_ord[PBA_OVL_WAVES][PBA_OVL_RUNS];        // ordinal of the position
+    __shared__ uint32_t r_key[HASHED ? PBA_OVL_WAVES : 1][HASHED ? PBA_OVL_RUNS : 1];
+    __shared__ uint32_t cursor, nvalid;
+    const uint32_t tl = blockIdx.x, t = t_lo + tl;
+    const int lane = threadIdx.x & (PBA_WAVE - 1), w = threadIdx.x / PBA_WAVE;
+    if (threadIdx.x == 0) { cursor = 0; nvalid = 0; }
+    __syncthreads();
+    const int len = (int)Rd.len[t];
+    const uint8_t *seq = Rd.packed + Rd.off[t];
+    const TargetWalk tw(len);
+    uint64_t *out = cand + cand_off[tl];
+    uint32_t myvalid = 0;
+    // every wavefront runs the same number of steps (the ballots and shuffles below need all its lanes; a lane past the
+    // end just has nothing to contribute)
+    const int steps = (tw.nchunks + PBA_WAVE * PBA_OVL_WAVES - 1) / (PBA_WAVE * PBA_OVL_WAVES);
+    for (int st = 0; st < steps; ++st) {
+        const int c = st * PBA_WAVE * PBA_OVL_WAVES + (int)threadIdx.x;
+        const bool live = c < tw.nchunks;
+        const uint64_t be = live ? chunk_bits(seq, (uint32_t)c) : 0ull;
+        uint32_t b[PBA_OVL_PPT], pw[PBA_OVL_PPT], key[PBA_OVL_PPT];
+#pragma unroll
+        for (int k = 0; k < PBA_OVL_PPT; ++k) {
+            key[k] = __builtin_bswap32((uint32_t)((be << (2 * k)) >> 32)) & T.mask;
+            const bool ok = live && key[k] != 0u && tw.ord_of(16 * c + k) >= 0;
+            b[k] = ok ? pt_bucket<HASHED>(T, key[k]) : 0xFFFFFFFFu;
+            pw[k] = T.presence[ok ? b[k] >> 5 : 0u];
+        }
+        uint32_t s0[PBA_OVL_PPT], n[PBA_OVL_PPT], tot = 0, nruns = 0;
+#pragma unroll
+        for (int k = 0; k < PBA_OVL_PPT; ++k) {
+            const bool hit = b[k] != 0xFFFFFFFFu && ((pw[k] >> (b[k] & 31)) & 1u);
+            const uint32_t *sp = T.start + (hit ? b[k] : 0u);
+            const uint32_t a0 = sp[0], a1 = sp[1];
+            s0[k] = a0; n[k] = hit ? a1 - a0 : 0u;
+            tot += n[k]; nruns += n[k] != 0u;
+        }
+        // exclusive prefix over the lanes: where this lane's runs go in the run list, and its entries in the reservation
+        uint32_t run_at = nruns, slot_at = tot;
+#pragma unroll
+        for (int d = 1; d < PBA_WAVE; d <<= 1) {
+            const uint32_t a = __shfl_up(run_at, d, PBA_WAVE), s = __shfl_up(slot_at, d, PBA_WAVE);
+            if (lane >= d) { run_at += a; slot_at += s; }
+        }
+        const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)run_at, PBA_WAVE - 1);
+        const uint32_t Tot = (uint32_t)__builtin_amdgcn_readlane((int)slot_at, PBA_WAVE - 1);
+        if (R == 0) continue;                                        // (wave-uniform)
+        run_at -= nruns; slot_at -= tot;
+#pragma unroll
+        for (int k = 0; k < PBA_OVL_PPT; ++k) {
+            if (n[k]) {
+                r_s0[w][run_at] = s0[k]; r_rel[w][run_at] = slot_at; r_ord[w][run_at] = (uint16_t)tw.ord_of(16 * c + k);
+                if (HASHED) r_key[w][run_at] = key[k];
+                ++run_at; slot_at += n[k];
+            }
+        }
+        if (lane == PBA_WAVE - 1) r_rel[w][R] = Tot;
+        // (every lane calls the atomic, lane 0 adds: the lane-0-only form is what ROCm 7.2's clang miscompiles in loops,
+        // tools/ubench_queue.hip)
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&cursor, lane == 0 ? Tot : 0u));
+        __builtin_amdgcn_wave_barrier();                             // the run list is this wavefront's own: LDS keeps its order
+        for (uint32_t r = (uint32_t)lane; r < R; r += PBA_WAVE) {
+            const uint32_t e0 = r_s0[w][r], rel = r_rel[w][r], cnt = r_rel[w][r + 1] - rel;
+            const uint64_t lowbits = (uint64_t)r_ord[w][r];
+            const uint32_t want = HASHED ? r_key[w][r] : 0u;
+            uint64_t *o = out + base + rel;
+            for (uint32_t h = 0; h < cnt; ++h) {
+                const uint32_t pe = T.pid[e0 + h];
+                const uint32_t q = pe >> PBA_OVL_JD_BITS;
+                bool ok = q != t;
+                if (HASHED) ok = ok && T.pkey[e0 + h] == want;
+                o[h] = ok ? ((uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pe & ((1u << PBA_OVL_JD_BITS) - 1)) << PBA_OVL_ORD_BITS | lowbits)
+                          : ~0ull;
+                myvalid += ok;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                             // before the next step overwrites the list
+    }
+#pragma unroll
+    for (int d = 1; d < PBA_WAVE; d <<= 1) myvalid += __shfl_xor(myvalid, d, PBA_WAVE);
+    if (lane == 0 && myvalid) atomicAdd(&nvalid, myvalid);
+    __syncthreads();
+    if (threadIdx.x == 0) valid[tl] = nvalid;
+}
+
+// A target whose slice outgrows one LDS sort (a million reads put 57 000 candidates on a target) is cut into pieces of
+// consecutive queries first: PBA_OVL_SUB fine buckets (bucket = umulhi(q, 2^32 * SUB / n_reads), monotone in q; the
+// all-ones slots go last), neighbours merged greedily into pieces that fit, the slice scattered piece by piece into a
+// second buffer -- the pieces in order are the list in query order, and each is then sorted on its own back into the
+// candidate array (k_piece_sort).  A piece that still does not fit (one query with tens of thousands of candidates on one
+// target: tandem repeats) is reported for the global bitonic pass.
+#define PBA_OVL_SUB 256
+struct OvlPiece { uint32_t off, n; };
+static __global__ void __launch_bounds__(1024)
+k_ovl_split(const uint32_t *big, const uint32_t *cand_off, const uint64_t *cand, uint64_t *tmp, uint32_t sub_mul,
+            OvlPiece *pieces, uint32_t *n_pieces, uint32_t *max_piece) {
+    __shared__ uint32_t hist[PBA_OVL_SUB], piece_of[PBA_OVL_SUB], pstart[PBA_OVL_SUB], pcur[PBA_OVL_SUB];
+    __shared__ uint32_t np_s, pbase_s;
+    const uint32_t tl = big[blockIdx.x];
+    const uint32_t lo = cand_off[tl], n = cand_off[tl + 1] - lo;
+    for (uint32_t i = threadIdx.x; i < PBA_OVL_SUB; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    auto bucket = [&](uint64_t cd) {
+        return cd == ~0ull ? (uint32_t)PBA_OVL_SUB - 1 : min((uint32_t)PBA_OVL_SUB - 1, __umulhi((uint32_t)(cd >> PBA_OVL_Q_SHIFT), sub_mul));
+    };
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(cand[lo + i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t np = 0, acc = 0, at = 0;
+        pstart[0] = 0;
+        for (uint32_t b = 0; b < PBA_OVL_SUB; ++b) {
+            if (acc && acc + hist[b] > PBA_IX_LDS_SORT_CAP) { pstart[++np] = at; acc = 0; }   // close the piece before bucket b
+            piece_of[b] = np;
+            acc += hist[b]; at += hist[b];
+        }
+        np_s = np + 1;
+        pbase_s = atomicAdd(n_pieces, np + 1);
+    }
+    __syncthreads();
+    const uint32_t np = np_s;
+    for (uint32_t p = threadIdx.x; p < np; p += blockDim.x) {
+        const uint32_t end = p + 1 < np ? pstart[p + 1] : n;
+        pieces[pbase_s + p] = OvlPiece{lo + pstart[p], end - pstart[p]};
+        if (end - pstart[p] <= PBA_IX_LDS_SORT_CAP) atomicMax(max_piece, end - pstart[p]);
+        pcur[p] = pstart[p];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t cd = cand[lo + i];
+        tmp[lo + atomicAdd(&pcur[piece_of[bucket(cd)]], 1u)] = cd;
+    }
+}
+// one workgroup sorts one piece in LDS, from src into dst (bitonic network on 64-bit entries); oversize pieces are left
+// to the host's global pass
+static __global__ void __launch_bounds__(1024)
+k_piece_sort(const uint64_t *src, uint64_t *dst, const OvlPiece *pieces) {
+    extern __shared__ __align__(16) uint64_t s_ent[];
+    const uint32_t lo = pieces[blockIdx.x].off, n = pieces[blockIdx.x].n;
+    if (n > PBA_IX_LDS_SORT_CAP) return;
+    uint32_t N = 2;
+    while (N < n) N <<= 1;
+    for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s_ent[i] = i < n ? src[lo + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i | j;
+                const uint64_t x = s_ent[i], y = s_ent[l];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) { s_ent[i] = y; s_ent[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[lo + i] = s_ent[i];
 }
 
 // work item i of a call = (target, first candidate of its group of 64): item_pre[t] = items of the targets before t
@@ -195,7 +468,7 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
 // candidate with the reference band until the first success or the end of the query's candidates.
 template <int NB>
 static __global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 4 ? 6 : 3))
-k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off,
+k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint32_t *cand_cnt,
            const uint64_t *cand, OvlCfg cfg, int full_band, const uint2 *redo_in, uint2 *redo_out, unsigned long long redo_cap,
            unsigned long long *n_redo_out, pba_overlap *out, unsigned long long cap, unsigned long long *n_out,
            unsigned long long *n_pairs, uint32_t *queue) {
@@ -218,10 +491,10 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
         const uint32_t NONE = 0xFFFFFFFFu;
         uint32_t tl, c_begin, c_end, own_end, skip_q = NONE, only_q = NONE;
         if (redo_in) {
-            tl = redo_in[item].x; c_begin = redo_in[item].y; c_end = own_end = cand_off[tl + 1];
+            tl = redo_in[item].x; c_begin = redo_in[item].y; c_end = own_end = cand_off[tl] + cand_cnt[tl];
             only_q = (uint32_t)(cand[c_begin] >> PBA_OVL_Q_SHIFT);
         } else {
-            tl = items[item].x; c_begin = items[item].y; c_end = cand_off[tl + 1];
+            tl = items[item].x; c_begin = items[item].y; c_end = cand_off[tl] + cand_cnt[tl];
             own_end = min(c_begin + (uint32_t)PBA_WAVE, c_end);
             if (c_begin > cand_off[tl]) skip_q = (uint32_t)(cand[c_begin - 1] >> PBA_OVL_Q_SHIFT);   // a run begun in the previous group
         }

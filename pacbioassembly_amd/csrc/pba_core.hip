@@ -308,6 +308,52 @@ int pba_seqs_from_records(pba_ctx *ctx, const uint8_t *file, size_t file_len, ui
     return PBA_OK;
 }
 
+int pba_seqs_export(pba_ctx *ctx, const pba_seqs *s, void *d_dst, uint64_t cap, uint64_t *offsets) {
+    if (!ctx || !s || !offsets || (!d_dst && s->packed_bytes)) return PBA_E_INVALID;
+    if (cap < s->packed_bytes) PBA_FAIL(PBA_E_INVALID, "pba_seqs_export: buffer smaller than pba_seqs_packed_bytes");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (s->packed_bytes) HIPCHK(hipMemcpyAsync(d_dst, s->d_packed, s->packed_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    for (uint32_t i = 0; i < s->n; ++i) offsets[i] = s->h_off[i];
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+int pba_seqs_from_device_packed(pba_ctx *ctx, const void *d_packed, uint64_t n_bytes, const uint64_t *offsets, const uint32_t *lengths,
+                                uint32_t n, int non_acgt, pba_seqs **out) {
+    if (!ctx || !out || (!d_packed && n_bytes) || (n && (!offsets || !lengths))) return PBA_E_INVALID;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    pba_seqs *s = new (std::nothrow) pba_seqs();
+    if (!s) PBA_FAIL(PBA_E_NOMEM, "pba_seqs");
+    s->ctx = ctx; s->n = n; s->max_len = 0; s->non_acgt = non_acgt != 0; s->d_alloc = nullptr; s->d_packed = nullptr; s->d_off = nullptr; s->d_len = nullptr; s->d_planes = nullptr; s->d_poff = nullptr; s->plane_words = 0;
+    s->h_off.resize((size_t)n + 1); s->h_len.resize((size_t)n + 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (offsets[i] + ((uint64_t)lengths[i] + 3) / 4 > n_bytes) { delete s; PBA_FAIL(PBA_E_INVALID, "pba_seqs_from_device_packed: sequence outside the buffer"); }
+        s->h_off[i] = offsets[i]; s->h_len[i] = lengths[i];
+        s->max_len = std::max(s->max_len, lengths[i]);
+    }
+    s->h_off[n] = n_bytes; s->h_len[n] = 0;
+    s->packed_bytes = n_bytes;
+    // like a binary read file: the bytes go in as they are, offsets point into them; slack on both sides for the streaming reads
+    hipError_t e = hipMalloc((void **)&s->d_alloc, n_bytes + 2 * kSlack);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_alloc, 0, kSlack, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_alloc + kSlack + n_bytes, 0, kSlack, ctx->stream);
+    if (e == hipSuccess) s->d_packed = s->d_alloc + kSlack;
+    if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(s->d_packed, d_packed, n_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_off, sizeof(uint64_t) * ((size_t)n + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_len, sizeof(uint32_t) * ((size_t)n + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_len, s->h_len.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { pba_seqs_destroy(s); return ctx_fail(ctx, PBA_E_HIP, "pba_seqs_from_device_packed", e); }
+    const int stp = seqs_planes(ctx, s);
+    if (stp != PBA_OK) { pba_seqs_destroy(s); return stp; }
+    *out = s;
+    return PBA_OK;
+}
+
+int pba_seqs_non_acgt(const pba_seqs *s) { return s && s->non_acgt ? 1 : 0; }
+
 uint32_t pba_seqs_count(const pba_seqs *s) { return s ? s->n : 0; }
 uint32_t pba_seqs_max_len(const pba_seqs *s) { return s ? s->max_len : 0; }
 uint64_t pba_seqs_packed_bytes(const pba_seqs *s) { return s ? s->packed_bytes : 0; }

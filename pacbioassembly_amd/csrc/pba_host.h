@@ -93,6 +93,7 @@ struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     template <class T> T *as() const { return (T *)p; }
+    void reset() { if (p) (void)hipFree(p); p = nullptr; }
 };
 
 // ---------------------------------------------------------------------------------------------

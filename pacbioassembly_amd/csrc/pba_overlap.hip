@@ -20,11 +20,21 @@ extern "C" {
 #define PBA_OVL_WALK(NBV)                                                                                             \
     hipLaunchKernelGGL((k_ovl_walk<NBV>), dim3(persistent_grid(ctx, n_items, (NBV) ? 4 : 1, lds)),                        \
                        dim3(PBA_WAVE * ((NBV) ? 4 : 1)), lds * ((NBV) ? 4 : 1), ctx->stream, reads->dev(), t_lo, n_items,  \
-                       items, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, full_band, redo_in,                     \
-                       d_redo.as<uint2>(),                                                                              \
+                       items, d_off.as<uint32_t>(), d_valid.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, full_band,       \
+                       redo_in, d_redo.as<uint2>(),                                                                      \
                        (unsigned long long)redo_cap, d_cnt64.as<unsigned long long>() + 2, d_out.as<pba_overlap>(),     \
                        (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1,  \
                        ctx->d_queue)
+
+// the probe table of a read set (overlap.h: ProbeTab), built once and scanned by every target range
+struct pba_probe_table {
+    int device;
+    ProbeTab T;
+    bool hashed;
+    uint32_t t2;
+    uint64_t n_entries;
+    float build_ms;
+};
 
 int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint32_t q_hi, uint32_t mask, int max_trial,
                        void *d_entries, uint64_t cap, uint64_t *n_out) {
@@ -72,10 +82,101 @@ int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t
 int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, const void *d_probe_entries,
                            uint64_t n_probe_slots, uint32_t mask, double R, int max_trial, int overlap_min, int kernel,
                            pba_overlap *out, uint64_t cap, uint64_t *n_out, pba_overlap_stats *stats) {
-    if (!ctx || !reads || !n_out || (!out && cap) || t_lo > t_hi || t_hi > reads->n || (!d_probe_entries && n_probe_slots))
-        return PBA_E_INVALID;
+    if (!ctx || !n_out) return PBA_E_INVALID;
+    pba_probe_table *tab = nullptr;
+    int rc = pba_probe_table_create(ctx, d_probe_entries, n_probe_slots, mask, max_trial, &tab);
+    if (rc != PBA_OK) return rc;
+    rc = pba_overlap_all_table(ctx, reads, t_lo, t_hi, tab, R, overlap_min, kernel, out, cap, n_out, stats);
+    pba_probe_table_destroy(tab);
+    return rc;
+}
+
+void pba_probe_table_destroy(pba_probe_table *t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->T.start) (void)hipFree(t->T.start);
+    if (t->T.pid) (void)hipFree(t->T.pid);
+    if (t->T.pkey) (void)hipFree(t->T.pkey);
+    if (t->T.presence) (void)hipFree(t->T.presence);
+    delete t;
+}
+
+uint64_t pba_probe_table_entries(const pba_probe_table *t) { return t ? t->n_entries : 0; }
+
+int pba_probe_table_create(pba_ctx *ctx, const void *d_probe_entries, uint64_t n_probe_slots, uint32_t mask, int max_trial,
+                           pba_probe_table **out) {
+    if (!ctx || !out || (!d_probe_entries && n_probe_slots)) return PBA_E_INVALID;
+    *out = nullptr;
     if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
-    if (reads->n >= (1u << 24)) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: at most 2^24 reads");
+    if (n_probe_slots >= PBA_OVL_MAX_PROBES) PBA_FAIL(PBA_E_TOOLONG, "probe table: 2^32 probe slots or more (reads x 2 x max_trial)");
+    HIPCHK(hipSetDevice(ctx->device));
+    pba_probe_table *t = new (std::nothrow) pba_probe_table();
+    if (!t) PBA_FAIL(PBA_E_NOMEM, "pba_probe_table");
+    memset(t, 0, sizeof *t);
+    t->device = ctx->device; t->t2 = 2u * (uint32_t)max_trial;
+    struct Guard { pba_probe_table *p; ~Guard() { pba_probe_table_destroy(p); } } guard{t};
+    const int care = __builtin_popcount(mask);
+    t->hashed = care > PBA_PT_MAX_BITS;
+    ProbeTab &T = t->T;
+    T.mask = mask; T.bits = t->hashed ? PBA_PT_MAX_BITS : care;
+    if (!t->hashed) {
+        uint32_t m = mask, mk = ~m << 1;                         // Hacker's Delight 7-4: the move masks of compress(x, m)
+        for (int i = 0; i < 5; ++i) {
+            uint32_t mp = mk ^ (mk << 1);
+            mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
+            const uint32_t mv = mp & m;
+            T.mv[i] = mv;
+            m = (m ^ mv) | (mv >> (1 << i));
+            mk &= ~mp;
+        }
+    }
+    const uint64_t B = 1ull << T.bits, pres_words = std::max<uint64_t>(1, B / 32);
+    HIPCHK(hipMalloc((void **)&T.start, sizeof(uint32_t) * (B + 1)));
+    HIPCHK(hipMalloc((void **)&T.presence, sizeof(uint32_t) * pres_words));
+    HIPCHK(hipMemsetAsync(T.start, 0, sizeof(uint32_t) * (B + 1), ctx->stream));
+    HIPCHK(hipMemsetAsync(T.presence, 0, sizeof(uint32_t) * pres_words, ctx->stream));
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    const uint64_t n = n_probe_slots;
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    const uint64_t *ent = (const uint64_t *)d_probe_entries;
+    if (grid) {
+        if (t->hashed) hipLaunchKernelGGL(k_pt_count<true>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T);
+        else hipLaunchKernelGGL(k_pt_count<false>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T);
+    }
+    // start[b + 1] = entries of bucket b  ->  inclusive scan  ->  start[b] = first entry of bucket b
+    const uint32_t n_tiles = (uint32_t)((B + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
+    DevBuf d_tiles, d_cursor;
+    HIPCHK(hipMalloc(&d_tiles.p, sizeof(uint32_t) * n_tiles));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, T.start + 1, B, d_tiles.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, d_tiles.as<uint32_t>(), n_tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, T.start + 1, B, d_tiles.as<uint32_t>());
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, T.start + B, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    t->n_entries = total;
+    HIPCHK(hipMalloc((void **)&T.pid, sizeof(uint32_t) * ((uint64_t)total + 1)));
+    if (t->hashed) HIPCHK(hipMalloc((void **)&T.pkey, sizeof(uint32_t) * ((uint64_t)total + 1)));
+    if (total) {
+        HIPCHK(hipMalloc(&d_cursor.p, sizeof(uint32_t) * B));
+        HIPCHK(hipMemcpyAsync(d_cursor.p, T.start, sizeof(uint32_t) * B, hipMemcpyDeviceToDevice, ctx->stream));
+        if (t->hashed) hipLaunchKernelGGL(k_pt_fill<true>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T, d_cursor.as<uint32_t>(), t->t2);
+        else hipLaunchKernelGGL(k_pt_fill<false>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T, d_cursor.as<uint32_t>(), t->t2);
+    }
+    (void)hipEventRecord(ctx->ev[1], ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    (void)hipEventElapsedTime(&t->build_ms, ctx->ev[0], ctx->ev[1]);
+    guard.p = nullptr;
+    *out = t;
+    return PBA_OK;
+}
+
+int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t t_hi, const pba_probe_table *tab, double R,
+                          int overlap_min, int kernel, pba_overlap *out, uint64_t cap, uint64_t *n_out, pba_overlap_stats *stats) {
+    if (!ctx || !reads || !tab || !n_out || (!out && cap) || t_lo > t_hi || t_hi > reads->n) return PBA_E_INVALID;
+    if (reads->n >= PBA_OVL_MAX_READS) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: at most 2^24 reads");
+    if ((uint64_t)reads->n * tab->t2 >= PBA_OVL_MAX_PROBES) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: reads x 2 x max_trial must stay below 2^32");
     if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
     if (reads->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "pba_overlap_all: the read set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
@@ -83,127 +184,102 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     *n_out = 0;
     pba_overlap_stats st;
     memset(&st, 0, sizeof st);
-    const uint32_t n = reads->n, nt = t_hi - t_lo, t2 = 2u * (uint32_t)max_trial;
+    st.n_probe_entries = tab->n_entries;
+    st.table_ms = tab->build_ms;
+    const uint32_t n = reads->n, nt = t_hi - t_lo, t2 = tab->t2;
     if (nt == 0 || n < 2) { if (stats) *stats = st; return PBA_OK; }
     Plan pl;
     int rc = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (rc != PBA_OK) return rc;
-
-    // 1. probe table: the (gathered) probe entries, partitioned and sorted like a seed index
+    const ProbeTab &T = tab->T;
     DevBuf d_cnt64;
     HIPCHK(hipMalloc(&d_cnt64.p, 32));
-    (void)hipEventRecord(ctx->ev[2], ctx->stream);
-    pba_index *pix = nullptr;
-    rc = pba_index_from_entries(ctx, d_probe_entries, n_probe_slots, mask, PBA_INDEX_ALL, 0, &pix);   // identity ordinal -> value: the probe id
-    if (rc != PBA_OK) return rc;
-    struct IxGuard { pba_index *p; ~IxGuard() { pba_index_destroy(p); } } guard{pix};
-    st.n_probe_entries = pix->n_entries;
 
-    // 2. scan the targets' positions against the probe table: count, offsets, fill
-    DevBuf d_off, d_cur, d_cand, d_out, d_pres;
-    HIPCHK(hipMalloc(&d_pres.p, (size_t)1 << (PBA_OVL_PRES_LOG - 3)));
-    HIPCHK(hipMemsetAsync(d_pres.p, 0, (size_t)1 << (PBA_OVL_PRES_LOG - 3), ctx->stream));
-    if (pix->n_entries)
-        hipLaunchKernelGGL(k_ovl_presence, dim3((uint32_t)((pix->n_entries + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)pix->d_ent, (uint64_t)pix->n_entries, d_pres.as<uint32_t>());
-    // a direct-address directory of the probe keys (seed_index.h: KeyDir), when the mask's care bits allow one
-    KeyDir kd;
-    memset(&kd, 0, sizeof kd);
-    DevBuf d_dir;
-    const int care = __builtin_popcount(mask);
-    if (pix->n_entries && pix->n_entries < 0xFFFFFFFFull && care <= PBA_DIR_MAX_BITS) {
-        kd.mask = mask; kd.n_entries = (uint32_t)pix->n_entries;
-        uint32_t m = mask, mk = ~m << 1;                         // Hacker's Delight 7-4: the move masks of compress(x, m)
-        for (int i = 0; i < 5; ++i) {
-            uint32_t mp = mk ^ (mk << 1);
-            mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
-            const uint32_t mv = mp & m;
-            kd.mv[i] = mv;
-            m = (m ^ mv) | (mv >> (1 << i));
-            mk &= ~mp;
-        }
-        HIPCHK(hipMalloc(&d_dir.p, sizeof(uint32_t) << care));
-        HIPCHK(hipMemsetAsync(d_dir.p, 0xFF, sizeof(uint32_t) << care, ctx->stream));
-        hipLaunchKernelGGL(k_dir_build, dim3((kd.n_entries + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)pix->d_ent,
-                           kd.n_entries, kd, d_dir.as<uint32_t>());
-        kd.dir = d_dir.as<uint32_t>();
-    }
+    // 1. count: the slice of the candidate array every target needs
+    DevBuf d_slice, d_off, d_valid, d_cand, d_tmp, d_out;
+    HIPCHK(hipMalloc(&d_slice.p, sizeof(uint32_t) * (nt + 1)));
     HIPCHK(hipMalloc(&d_off.p, sizeof(uint32_t) * (nt + 1)));
-    // count per (target, bucket of consecutive queries): PBA_OVL_SUB buckets per target
-    const uint64_t nsub = (uint64_t)nt * PBA_OVL_SUB;
-    const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // bucket = umulhi(q, sub_mul)
-    DevBuf d_sub;
-    HIPCHK(hipMalloc(&d_sub.p, sizeof(uint32_t) * (nsub + 1)));
-    hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), kd, d_pres.as<uint32_t>(), reads->dev(),
-                       t_lo, nt, t2, sub_mul, 0, d_sub.as<uint32_t>(), (uint64_t *)nullptr);
-    std::vector<uint32_t> h_sub(nsub + 1), h_cnt(nt + 1), h_off(nt + 1);
-    HIPCHK(hipMemcpyAsync(h_sub.data(), d_sub.p, sizeof(uint32_t) * nsub, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMalloc(&d_valid.p, sizeof(uint32_t) * (nt + 1)));
+    (void)hipEventRecord(ctx->ev[2], ctx->stream);
+    if (tab->hashed) hipLaunchKernelGGL(k_ovl_count<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+    else hipLaunchKernelGGL(k_ovl_count<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+    std::vector<uint32_t> h_slice(nt + 1), h_off(nt + 1), h_valid(nt + 1);
+    HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-    // the coarsest split (2^shift neighbouring buckets merged) whose pieces all fit the LDS sort
-    int shift = 0;
-    for (int sh = 6; sh >= 0; --sh) {                            // PBA_OVL_SUB = 2^6
-        bool fits = true;
-        for (uint64_t p0 = 0; p0 < nsub && fits; p0 += (1ull << sh)) {
-            uint64_t c = 0;
-            for (uint64_t k = 0; k < (1ull << sh); ++k) c += h_sub[p0 + k];
-            fits = c <= PBA_IX_LDS_SORT_CAP;
-        }
-        if (fits) { shift = sh; break; }
-    }
-    const uint32_t per_t = PBA_OVL_SUB >> shift;                  // sorted pieces per target
-    const uint64_t npiece = (uint64_t)nt * per_t;
-    std::vector<uint32_t> h_poff(npiece + 1);
     uint64_t total = 0;
-    uint32_t biggest = 2;
-    std::vector<uint32_t> oversize;                               // pieces that outgrow the LDS sort even at the finest split
+    uint32_t biggest_small = 2;
+    std::vector<uint32_t> big;                                   // targets whose slice outgrows one LDS sort
     for (uint32_t i = 0; i < nt; ++i) {
         h_off[i] = (uint32_t)total;
-        for (uint32_t pc = 0; pc < per_t; ++pc) {
-            uint64_t c = 0;
-            for (uint32_t k = 0; k < (1u << shift); ++k) c += h_sub[(uint64_t)i * PBA_OVL_SUB + ((uint64_t)pc << shift) + k];
-            h_poff[(uint64_t)i * per_t + pc] = (uint32_t)total;
-            if (c <= PBA_IX_LDS_SORT_CAP) biggest = std::max<uint32_t>(biggest, (uint32_t)c);
-            else oversize.push_back((uint32_t)((uint64_t)i * per_t + pc));
-            total += c;
-            if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: more than 2^32 candidates in one target range; shard it");
-        }
-        h_cnt[i] = (uint32_t)(total - h_off[i]);
+        total += h_slice[i];
+        if (total >= PBA_OVL_MAX_CANDIDATES) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
+        if (h_slice[i] <= PBA_IX_LDS_SORT_CAP) biggest_small = std::max(biggest_small, h_slice[i]);
+        else big.push_back(i);
     }
     h_off[nt] = (uint32_t)total;
-    h_poff[npiece] = (uint32_t)total;
-    st.n_candidates = total;
-    DevBuf d_poff;
-    HIPCHK(hipMalloc(&d_cand.p, sizeof(uint64_t) * (total + 1)));
-    HIPCHK(hipMalloc(&d_poff.p, sizeof(uint32_t) * (npiece + 1)));
-    HIPCHK(hipMalloc(&d_cur.p, sizeof(uint32_t) * (npiece + 1)));
     HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_poff.p, h_poff.data(), sizeof(uint32_t) * (npiece + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_cur.p, h_poff.data(), sizeof(uint32_t) * (npiece + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMalloc(&d_cand.p, sizeof(uint64_t) * (total + 1)));
+
+    // 2. fill: the candidates (all-ones where a slot belongs to the target's own probe or to another key)
     if (total) {
-        hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(256), 0, ctx->stream, pix->dev(), kd, d_pres.as<uint32_t>(),
-                           reads->dev(), t_lo, nt, t2, sub_mul, shift, d_cur.as<uint32_t>(), d_cand.as<uint64_t>());
-        (void)hipEventRecord(ctx->ev[3], ctx->stream);
-        // 3. sort every piece = the reference's try order inside every (target, query); the pieces of a target in
-        //    order are its list in query order
-        uint32_t pow2 = 2;
-        while (pow2 < biggest) pow2 <<= 1;
-        for (uint64_t p0 = 0; p0 < npiece; p0 += 0x40000000ull) {  // (grid dimension limit)
-            const uint32_t chunk = (uint32_t)std::min<uint64_t>(npiece - p0, 0x40000000ull);
-            // (a big piece takes most of a CU's LDS, so its workgroup is the only one there: 1 024 threads keep the CU busy)
-            hipLaunchKernelGGL(k_part_sort, dim3(chunk), dim3(pow2 >= 4096 ? 1024 : 256), sizeof(uint64_t) * pow2, ctx->stream, d_cand.as<uint64_t>(),
-                               d_poff.as<uint32_t>() + p0);
-        }
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipGetLastError());
-        for (uint32_t pc : oversize) {                            // e.g. one query with > 16 384 candidates on a target
-            rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_poff[pc], h_poff[pc + 1] - h_poff[pc]);
-            if (rc != PBA_OK) return rc;
-        }
+        if (tab->hashed) hipLaunchKernelGGL(k_ovl_fill<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>());
+        else hipLaunchKernelGGL(k_ovl_fill<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>());
+        HIPCHK(hipMemcpyAsync(h_valid.data(), d_valid.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
     } else {
-        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        HIPCHK(hipMemsetAsync(d_valid.p, 0, sizeof(uint32_t) * (nt + 1), ctx->stream));
+    }
+    (void)hipEventRecord(ctx->ev[3], ctx->stream);
+
+    // 3. sort every target's slice = the reference's try order inside every (target, query): in LDS, in place; the big
+    //    ones piece by piece through a second buffer
+    if (total) {
+        uint32_t pow2 = 2;
+        while (pow2 < biggest_small) pow2 <<= 1;
+        // (a big slice takes most of a CU's LDS, so its workgroup is the only one there: 1 024 threads keep the CU busy)
+        hipLaunchKernelGGL(k_part_sort, dim3(nt), dim3(pow2 >= 4096 ? 1024 : 256), sizeof(uint64_t) * pow2, ctx->stream,
+                           d_cand.as<uint64_t>(), d_off.as<uint32_t>());
+        if (!big.empty()) {
+            st.n_big_targets = (uint32_t)big.size();
+            DevBuf d_big, d_pieces, d_pc;
+            const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // fine bucket = umulhi(q, sub_mul)
+            HIPCHK(hipMalloc(&d_tmp.p, sizeof(uint64_t) * (total + 1)));
+            HIPCHK(hipMalloc(&d_big.p, sizeof(uint32_t) * big.size()));
+            HIPCHK(hipMalloc(&d_pieces.p, sizeof(OvlPiece) * big.size() * PBA_OVL_SUB));
+            HIPCHK(hipMalloc(&d_pc.p, 8));
+            HIPCHK(hipMemsetAsync(d_pc.p, 0, 8, ctx->stream));
+            HIPCHK(hipMemcpyAsync(d_big.p, big.data(), sizeof(uint32_t) * big.size(), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_ovl_split, dim3((uint32_t)big.size()), dim3(1024), 0, ctx->stream, d_big.as<uint32_t>(), d_off.as<uint32_t>(),
+                               d_cand.as<uint64_t>(), d_tmp.as<uint64_t>(), sub_mul, d_pieces.as<OvlPiece>(), d_pc.as<uint32_t>(),
+                               d_pc.as<uint32_t>() + 1);
+            uint32_t h_pc[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(h_pc, d_pc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipGetLastError());
+            uint32_t p2 = 2;
+            while (p2 < h_pc[1]) p2 <<= 1;
+            hipLaunchKernelGGL(k_piece_sort, dim3(h_pc[0]), dim3(p2 >= 4096 ? 1024 : 256), sizeof(uint64_t) * p2, ctx->stream,
+                               d_tmp.as<uint64_t>(), d_cand.as<uint64_t>(), d_pieces.as<OvlPiece>());
+            std::vector<OvlPiece> h_pieces(h_pc[0]);
+            HIPCHK(hipMemcpyAsync(h_pieces.data(), d_pieces.p, sizeof(OvlPiece) * h_pc[0], hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipGetLastError());
+            for (const OvlPiece &pc : h_pieces)                   // e.g. one query with > 16 384 candidates on a target
+                if (pc.n > PBA_IX_LDS_SORT_CAP) {
+                    rc = sort_partition_global(ctx, d_tmp.as<uint64_t>() + pc.off, pc.n);
+                    if (rc != PBA_OK) return rc;
+                    HIPCHK(hipMemcpyAsync(d_cand.as<uint64_t>() + pc.off, d_tmp.as<uint64_t>() + pc.off, sizeof(uint64_t) * pc.n,
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+                }
+        }
     }
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    d_tmp.reset();                                               // (the second buffer goes before the walk allocates)
+    uint64_t n_valid = 0;
+    for (uint32_t i = 0; i < nt; ++i) n_valid += h_valid[i];
+    st.n_candidates = n_valid;
 
     // 4. walk: persistent wavefronts, one target at a time, narrow window; then the parked (target, query) runs
     //    at the reference band
@@ -214,13 +290,14 @@ int pba_overlap_all_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, u
     ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
     const size_t lds = pl.lds;
     DevBuf d_redo, d_items;
-    const uint64_t redo_cap = std::max<uint64_t>(1024, total / 4);
+    // every (target, query) run can park at most once per stage, and there are no more runs than candidates
+    const uint64_t redo_cap = std::max<uint64_t>(1024, n_valid);
     HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2) * redo_cap));
     // work items: (target, first candidate of a group of 64), expanded on the device from the per-target item counts
     // (a million reads make 22 M items per call: building and copying them from the host took longer than a scan pass)
     std::vector<uint32_t> h_ipre(nt + 1);
     uint64_t n_items64 = 0;
-    for (uint32_t i = 0; i < nt; ++i) { h_ipre[i] = (uint32_t)n_items64; n_items64 += (h_cnt[i] + PBA_WAVE - 1) / PBA_WAVE; }
+    for (uint32_t i = 0; i < nt; ++i) { h_ipre[i] = (uint32_t)n_items64; n_items64 += (h_valid[i] + PBA_WAVE - 1) / PBA_WAVE; }
     if (n_items64 >= 0xFFFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: too many work items per call, use a smaller target range");
     h_ipre[nt] = (uint32_t)n_items64;
     DevBuf d_ipre;

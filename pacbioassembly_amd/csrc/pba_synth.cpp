@@ -27,15 +27,16 @@ struct Stream {
 
 inline int code_of(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }
 
-void gen_reads(uint64_t seed, const char *genome, size_t L, uint32_t r0, uint32_t r1, uint32_t rl, uint64_t t_ins,
+// reads [r0, r1) of the set; read r goes to slot r - slot0 of out / starts
+void gen_reads(uint64_t seed, const char *genome, size_t L, uint32_t r0, uint32_t r1, uint32_t slot0, uint32_t rl, uint64_t t_ins,
                uint64_t t_del, uint64_t t_sub, char *out, uint32_t *starts) {
     const size_t span = (size_t)rl + rl / 2;
     const uint64_t nstart = L > span ? L - span : 1;
     for (uint32_t r = r0; r < r1; ++r) {
         Stream st(seed, r);
         size_t g = (size_t)(st.next() % nstart);
-        if (starts) starts[r] = (uint32_t)g;
-        char *o = out + (size_t)r * rl;
+        if (starts) starts[r - slot0] = (uint32_t)g;
+        char *o = out + (size_t)(r - slot0) * rl;
         uint32_t emitted = 0;
         while (emitted < rl) {
             const uint64_t x = st.next();
@@ -67,25 +68,31 @@ void pba_synth_genome(uint64_t seed, char *out, size_t n) {
     }
 }
 
-int pba_synth_reads(uint64_t seed, const char *genome, size_t L, uint32_t n_reads, uint32_t read_len, double p_ins,
-                    double p_del, double p_sub, char *out, uint32_t *starts, int nthreads) {
-    if (!genome || !out || L == 0 || read_len == 0) return PBA_E_INVALID;
+int pba_synth_reads_range(uint64_t seed, const char *genome, size_t L, uint32_t r_lo, uint32_t r_hi, uint32_t read_len, double p_ins,
+                          double p_del, double p_sub, char *out, uint32_t *starts, int nthreads) {
+    if (!genome || !out || L == 0 || read_len == 0 || r_lo > r_hi) return PBA_E_INVALID;
     if (p_ins < 0 || p_del < 0 || p_sub < 0 || p_ins + p_del + p_sub >= 1.0) return PBA_E_INVALID;
     const double two32 = 4294967296.0;
     const uint64_t t_ins = (uint64_t)(p_ins * two32);
     const uint64_t t_del = t_ins + (uint64_t)(p_del * two32);
     const uint64_t t_sub = t_del + (uint64_t)(p_sub * two32);
+    const uint32_t n_reads = r_hi - r_lo;
     if (nthreads < 1) nthreads = 1;
     if ((uint32_t)nthreads > n_reads) nthreads = n_reads ? (int)n_reads : 1;
     std::vector<std::thread> th;
     const uint32_t per = (n_reads + nthreads - 1) / nthreads;
     for (int t = 0; t < nthreads; ++t) {
-        const uint32_t r0 = (uint32_t)t * per, r1 = r0 + per < n_reads ? r0 + per : n_reads;
+        const uint32_t r0 = r_lo + (uint32_t)t * per, r1 = r0 + per < r_hi ? r0 + per : r_hi;
         if (r0 >= r1) break;
-        th.emplace_back(gen_reads, seed, genome, L, r0, r1, read_len, t_ins, t_del, t_sub, out, starts);
+        th.emplace_back(gen_reads, seed, genome, L, r0, r1, r_lo, read_len, t_ins, t_del, t_sub, out, starts);
     }
     for (auto &x : th) x.join();
     return PBA_OK;
+}
+
+int pba_synth_reads(uint64_t seed, const char *genome, size_t L, uint32_t n_reads, uint32_t read_len, double p_ins,
+                    double p_del, double p_sub, char *out, uint32_t *starts, int nthreads) {
+    return pba_synth_reads_range(seed, genome, L, 0, n_reads, read_len, p_ins, p_del, p_sub, out, starts, nthreads);
 }
 
 }  // extern "C"

@@ -108,6 +108,19 @@ def synth_reads(seed: int, genome: np.ndarray, n_reads: int, read_len: int, p_in
     return out, offs, starts[:n_reads]
 
 
+def synth_reads_range(seed: int, genome: np.ndarray, r_lo: int, r_hi: int, read_len: int, p_ins: float = 0.05,
+                      p_del: float = 0.05, p_sub: float = 0.05, nthreads: int = 8):
+    """Reads [r_lo, r_hi) of the set synth_reads(seed, ...) makes: (text, offsets) of just those reads."""
+    genome = np.ascontiguousarray(genome, np.uint8)
+    n = r_hi - r_lo
+    out = np.empty(max(n, 0) * read_len, np.uint8)
+    st = _lib.load().pba_synth_reads_range(seed, _ptr(genome), genome.size, r_lo, r_hi, read_len, p_ins, p_del, p_sub,
+                                           _ptr(out), None, nthreads)
+    if st != 0:
+        raise PbaError(st, "pba_synth_reads_range")
+    return out, (np.arange(n + 1, dtype=np.uint64) * np.uint64(read_len))
+
+
 def concat(seqs: Sequence[bytes]):
     """Concatenate byte strings into (text uint8[], offsets uint64[n+1])."""
     offs = np.zeros(len(seqs) + 1, np.uint64)
@@ -181,6 +194,16 @@ class Context:
         h = C.c_void_p()
         self.check(self.lib.pba_seqs_from_records(self.h, _ptr(buf), len(file), min_excl, max_excl, C.byref(h)),
                    "seqs_from_records")
+        return SeqSet(self, h)
+
+    def seqs_from_device_packed(self, d_packed_ptr: int, n_bytes: int, offsets: np.ndarray, lengths: np.ndarray,
+                                non_acgt: bool = False) -> "SeqSet":
+        """A set over packed bytes already on the device (the all-gathered read shards): no re-packing."""
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        lengths = np.ascontiguousarray(lengths, np.uint32)
+        h = C.c_void_p()
+        self.check(self.lib.pba_seqs_from_device_packed(self.h, C.c_void_p(d_packed_ptr), n_bytes, _ptr(offsets), _ptr(lengths),
+                                                        lengths.size, int(non_acgt), C.byref(h)), "seqs_from_device_packed")
         return SeqSet(self, h)
 
     # -- index
@@ -321,29 +344,69 @@ def _overlap_all_probes(self, reads, d_entries_ptr, n_slots, mask, R, max_trial=
     return out[:min(int(n.value), cap)], {k: getattr(st, k) for k, _ in _lib.PbaOverlapStats._fields_}
 
 
+class ProbeTable:
+    """The probe table of a read set (pba_probe_table): built once from a device entry list, scanned by every target range."""
+
+    def __init__(self, ctx, d_entries_ptr, n_slots, mask, max_trial):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx.check(ctx.lib.pba_probe_table_create(ctx.h, C.c_void_p(d_entries_ptr), n_slots, mask, max_trial, C.byref(self.h)),
+                  "probe_table_create")
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.pba_probe_table_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    @property
+    def entries(self) -> int:
+        return self.ctx.lib.pba_probe_table_entries(self.h)
+
+
+def _overlap_all_table(self, reads, table, R, overlap_min=64, t_lo=0, t_hi=None, kernel=PBA_KERNEL_AUTO, cap=None):
+    t_hi = reads.count if t_hi is None else t_hi
+    cap = cap if cap is not None else max(1, (t_hi - t_lo) * max(reads.count - 1, 1))
+    out = np.zeros(cap, OVERLAP_DTYPE)
+    n = C.c_uint64()
+    st = _lib.PbaOverlapStats()
+    self.check(self.lib.pba_overlap_all_table(self.h, reads.h, t_lo, t_hi, table.h, R, overlap_min, kernel, _ptr(out), cap,
+                                              C.byref(n), C.byref(st)), "overlap_all_table")
+    return out[:min(int(n.value), cap)], {k: getattr(st, k) for k, _ in _lib.PbaOverlapStats._fields_}
+
+
 def _overlap_all_sharded(self, reads, mask, R, max_trial=32, overlap_min=64, targets_per_call=10000, kernel=PBA_KERNEL_AUTO,
-                         cap_per_target=None):
+                         cap_per_target=None, t_lo=0, t_hi=None, table=None):
     """pba_overlap_all for read sets whose candidate lists do not fit one call (false candidates grow with the square of
-    the read count; a call takes at most 2^32): the probe table is built once on the device, the targets go through in
-    ranges.  Same result as one call (the ranges are independent: this is also what ranks of a multi-GPU run do)."""
+    the read count; a call takes at most 2^32): the probe table is built once on the device (or handed in: the multi-GPU
+    form builds it from the all-gathered entries), the targets [t_lo, t_hi) go through in ranges.  Same result as one call
+    (the ranges are independent: this is also what ranks of a multi-GPU run do)."""
     import torch
     n = reads.count
-    slots = n * 2 * max_trial
-    probes = torch.full((max(slots, 1),), -1, dtype=torch.int64, device="cuda")
-    self.overlap_probes(reads, 0, n, mask, max_trial, probes.data_ptr(), slots)
-    torch.cuda.synchronize()
+    t_hi = n if t_hi is None else t_hi
+    own = table is None
+    if own:
+        slots = n * 2 * max_trial
+        probes = torch.full((max(slots, 1),), -1, dtype=torch.int64, device="cuda")
+        self.overlap_probes(reads, 0, n, mask, max_trial, probes.data_ptr(), slots)
+        torch.cuda.synchronize()
+        table = ProbeTable(self, probes.data_ptr(), probes.numel(), mask, max_trial)
+        del probes
     parts, total = [], None
-    for lo in range(0, n, targets_per_call):
-        hi = min(n, lo + targets_per_call)
+    for lo in range(t_lo, t_hi, targets_per_call):
+        hi = min(t_hi, lo + targets_per_call)
         cap = (hi - lo) * (cap_per_target or max(n - 1, 1))
-        ov, st = self.overlap_all_probes(reads, probes.data_ptr(), probes.numel(), mask, R, max_trial, overlap_min, lo, hi, kernel, cap)
+        ov, st = self.overlap_all_table(reads, table, R, overlap_min, lo, hi, kernel, cap)
         parts.append(ov)
         if total is None:
             total = dict(st)
         else:
-            for k in ("n_candidates", "n_pairs", "n_overlaps", "n_redo", "scan_ms", "sort_ms", "walk_ms"):
+            for k in ("n_candidates", "n_pairs", "n_overlaps", "n_redo", "scan_ms", "sort_ms", "walk_ms", "n_big_targets"):
                 total[k] += st[k]
             total["wide_first"] = max(total["wide_first"], st["wide_first"])
+    if own:
+        table.close()
     out = np.concatenate(parts) if parts else np.zeros(0, OVERLAP_DTYPE)
     return out, (total or {})
 
@@ -352,6 +415,7 @@ Context.overlap_all = _overlap_all
 Context.overlap_probes = _overlap_probes
 Context.overlap_all_probes = _overlap_all_probes
 Context.overlap_all_sharded = _overlap_all_sharded
+Context.overlap_all_table = _overlap_all_table
 
 
 class SeqSet:
@@ -381,6 +445,16 @@ class SeqSet:
         out = np.zeros(max(self.count, 1), np.uint32)
         self.ctx.check(self.ctx.lib.pba_seqs_lengths(self.h, _ptr(out), self.count))
         return out[:self.count]
+
+    def export(self, d_dst_ptr: int, cap: int) -> np.ndarray:
+        """Copy the packed arena into a device buffer; returns the byte offset of every sequence in it."""
+        offs = np.zeros(max(self.count, 1), np.uint64)
+        self.ctx.check(self.ctx.lib.pba_seqs_export(self.ctx.h, self.h, C.c_void_p(d_dst_ptr), cap, _ptr(offs)), "seqs_export")
+        return offs[:self.count]
+
+    @property
+    def non_acgt(self) -> bool:
+        return bool(self.ctx.lib.pba_seqs_non_acgt(self.h))
 
     def get_text(self, i: int) -> bytes:
         ln = int(self.lengths()[i])

@@ -28,8 +28,16 @@ if a.targets_per_call > 0:
 else:
     ov, st = ctx.overlap_all(S, mask, a.R, a.trials, 64, cap=cap)
 dt = time.perf_counter() - t
+# scan roofline: algorithmic bytes = 0.25 B per visited position (the packed bases, read once) + 8 B per
+# candidate written; the scan makes two passes over the positions (slice sizes, then the candidates)
+visited = sum(min(a.read_len - 16, 20000) + max(0, min(a.read_len - 20016, 20000)) for _ in range(1)) * a.reads
+scan_bytes = visited * 0.25 + st["n_candidates"] * 8
+scan_gbs = scan_bytes / (st["scan_ms"] * 1e-3) / 1e9 if st["scan_ms"] > 0 else 0.0
 print(json.dumps({"workload": f"all-vs-all, {a.reads} x {a.read_len} reads @15%, genome {L} ({a.coverage}x), R={a.R}, {a.trials} trials/end",
                   "seconds": round(dt, 3), "overlaps": int(st["n_overlaps"]), "pairs": int(st["n_pairs"]),
                   "candidates": int(st["n_candidates"]), "pairs_per_s": round(st["n_pairs"] / dt, 1),
-                  "overlaps_per_s": round(st["n_overlaps"] / dt, 1), "scan_ms": st["scan_ms"], "sort_ms": st["sort_ms"],
-                  "walk_ms": st["walk_ms"]}))
+                  "overlaps_per_s": round(st["n_overlaps"] / dt, 1), "table_ms": st["table_ms"], "scan_ms": st["scan_ms"],
+                  "sort_ms": st["sort_ms"], "walk_ms": st["walk_ms"], "n_big_targets": st.get("n_big_targets", 0),
+                  "roofline_scan": {"bound": "hbm", "kernel": "k_ovl_count + k_ovl_fill", "achieved": round(scan_gbs, 1), "peak": 8000.0,
+                                    "unit": "GB/s", "frac": round(scan_gbs / 8000.0, 5), "positions": int(visited),
+                                    "algorithmic_bytes": int(scan_bytes), "positions_per_s": round(visited / (st["scan_ms"] * 1e-3), 1) if st["scan_ms"] > 0 else None}}))
