@@ -17,14 +17,13 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_index_exchange_gloo(lib, oracle, world):
+def run_world(worker, world):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -37,3 +36,15 @@ def test_index_exchange_gloo(lib, oracle, world):
         outs.append(o.decode())
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_index_exchange_gloo(lib, oracle, world):
+    run_world("dist_worker.py", world)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlap_exchange_gloo(lib, oracle, world):
+    """All-vs-all across ranks: packed read shards all-gathered, probe entries all-gathered, target shards walked per
+    rank and merged (overlap_probes -> all_gather_entries -> shard_range)."""
+    run_world("dist_overlap_worker.py", world)

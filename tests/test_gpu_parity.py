@@ -618,6 +618,54 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     assert [tuple(int(x) for x in r) for r in got3] == want and st3["n_pairs"] == st["n_pairs"]
 
 
+def test_read_shards_exported_and_regathered_give_the_same_overlaps(ctx):
+    """The multi-GPU read exchange in one process: three "ranks" pack their shards (one of them from a binary read file,
+    whose payloads are not 16-byte aligned), export the packed arenas into one padded buffer -- what the RCCL all-gather of
+    pacbioassembly_amd.distributed.all_gather_packed produces -- and the set rebuilt from that buffer gives the same reads,
+    the same probe table and the same overlaps as the set packed in one piece."""
+    import torch
+    g = eng.synth_genome(171, 7000)
+    n, rl = 48, 1200
+    reads, offs, _ = eng.synth_reads(172, g, n, rl)
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+    texts[7] = texts[7][:801]
+    texts[30] = texts[30][:650]
+    mask = eng.mask_from_pattern(MASK_PAT)
+    whole = ctx.seqs_from_list(texts, strict_acgt=True)
+    want, wst = ctx.overlap_all(whole, mask, 0.30, 32, 64)
+    assert len(want) > 60
+    shards = [(0, 17), (17, 33), (33, 48)]
+    sets = [ctx.seqs_from_list(texts[a:b], strict_acgt=True) if k != 1 else
+            ctx.seqs_from_records(b"".join(eng.text2bin(t) for t in texts[a:b]), 0, 1 << 30) for k, (a, b) in enumerate(shards)]
+    stride = (max(s.packed_bytes for s in sets) + 15) // 16 * 16
+    buf = torch.zeros(len(sets) * stride, dtype=torch.uint8, device="cuda")
+    all_offs, all_lens = [], []
+    for k, s in enumerate(sets):
+        o = s.export(buf[k * stride:].data_ptr(), stride)
+        all_offs.append(o + np.uint64(k * stride))
+        all_lens.append(s.lengths())
+    torch.cuda.synchronize()
+    S = ctx.seqs_from_device_packed(buf.data_ptr(), buf.numel(), np.concatenate(all_offs), np.concatenate(all_lens))
+    del buf
+    assert S.count == n and [S.get_text(i) for i in (0, 7, 17, 30, 47)] == [texts[i] for i in (0, 7, 17, 30, 47)]
+    assert not S.non_acgt
+    got, st = ctx.overlap_all(S, mask, 0.30, 32, 64)
+    assert [tuple(int(x) for x in r) for r in got] == [tuple(int(x) for x in r) for r in want]
+    assert st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"] and st["n_probe_entries"] == wst["n_probe_entries"]
+    # one probe table, many target ranges (pba_probe_table_*): the form ranks and the 10 M-read configuration use
+    cap = n * 64
+    probes = torch.full((cap,), -1, dtype=torch.int64, device="cuda")
+    assert ctx.overlap_probes(S, 0, n, mask, 32, probes.data_ptr(), cap) == st["n_probe_entries"]
+    from pacbioassembly_amd import ProbeTable
+    table = ProbeTable(ctx, probes.data_ptr(), cap, mask, 32)
+    assert table.entries == st["n_probe_entries"]
+    parts = [ctx.overlap_all_table(S, table, 0.30, 64, a, b)[0] for a, b in ((0, 5), (5, 6), (6, 48))]
+    assert [tuple(int(x) for x in r) for p in parts for r in p] == [tuple(int(x) for x in r) for r in want]
+    with pytest.raises(PbaError) as e:                               # a sequence that does not fit the buffer it is said to lie in
+        ctx.seqs_from_device_packed(probes.data_ptr(), 64, np.array([60], np.uint64), np.array([100], np.uint32))
+    assert e.value.status == -1
+
+
 def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):
     """6.5 kb reads at ~12 % error each overlap at ~24 % between them: the first-pass window (1 384 in a one-block ring)
     cannot certify the longest true overlaps, the (target, query) run is parked and resumed at the reference band by
