@@ -1,8 +1,9 @@
 // locator_gpu.cpp -- the reference's `locator` (src/locator.cpp) on the MI355X through the C ABI: same command line
-// (`locator_gpu contig_file seed [R] < seq_file`), same TSV on stdout -- columns 1-4 (running id among the reads of
-// >= 500 bases, contig position, cost, len - j).  The reference's 5th column is a cell of its DP matrix that is only
-// written when the contig remainder is longer than the read; there is no matrix here, so it is not printed.
-// R defaults to the reference's 0.15 (locator.cpp:68).
+// (`locator_gpu contig_file seed [R] < seq_file`), same TSV on stdout: running id among the reads of >= 500 bases,
+// contig position, cost, len - j, and get_cost(len - j, len - j) -- the cost at the end of the diagonal, a cell of the
+// reference's DP matrix that its sweep writes when the contig remainder is at least as long as the read remainder
+// (the reference prints stale memory otherwise, this prints -1).  R defaults to the reference's 0.15
+// (locator.cpp:68).
 //
 //   g++ -O2 -I include -o locator_gpu examples/locator_gpu.cpp -L pacbioassembly_amd/lib -lpba -Wl,-rpath,$PWD/pacbioassembly_amd/lib
 #include <stdio.h>
@@ -57,7 +58,9 @@ int main(int argc, char *argv[]) {
     // locator.cpp:68-92: 50 probe offsets, reads of >= 500 bases, seq_aligner<40000, 6000>
     if ((st = pba_locate(ctx, ix, T, 0, Rd, R, 50, 500, 40000, 6000, PBA_KERNEL_AUTO, rows.data(), &stats)) != PBA_OK) die(ctx, "locate", st);
     for (uint32_t i = 0; i < nreads; ++i)
-        if (rows[i].found) printf("%d\t%d\t%d\t%d\n", rows[i].nseq, rows[i].pos, rows[i].cost, rows[i].seglen);   // locator.cpp:84
+        if (rows[i].found)                                                                                           // locator.cpp:84-86
+            printf("%d\t%d\t%d\t%d\t%d\n", rows[i].nseq, rows[i].pos, rows[i].cost, rows[i].seglen,
+                   (long long)contig.size() - rows[i].pos >= rows[i].seglen ? rows[i].diag_cost : -1);
     fprintf(stderr, "totally %lld sequences processed\n", (long long)stats.n_reads_kept);
     pba_index_destroy(ix);
     pba_seqs_destroy(Rd);

@@ -3,8 +3,10 @@
 #ifndef PBA_COMPAT_COMMON_H
 #define PBA_COMPAT_COMMON_H
 
+#include <limits.h>      // INT_MAX, PATH_MAX: the reference's common.h pulls them in through <climits> (spaced_seed.cpp:92,360)
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <list>
 #include <unordered_map>

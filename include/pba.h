@@ -206,6 +206,8 @@ typedef struct {
     int32_t len_a;       /* parameter block, seq_aligner.h:94-102 */
     int32_t len_b;
     int32_t max_dst;
+    int32_t diag_cost;   /* get_cost(m, m), m = min(len_a, len_b): the end of the diagonal -- what locator.cpp:86 prints as
+                          * get_cost(len - j, len - j) when len_b >= len_a; -1 when the sweep stopped before that row */
 } pba_result;
 
 typedef enum {
@@ -230,6 +232,15 @@ int pba_align_text(pba_ctx *ctx, const char *a, int a_fwd, int a_len, const char
  * ((len_a+1) * (2*max_dst+1) bytes): for single pairs (display, the compat seq_aligner). */
 int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int a_len, const char *b, int b_fwd, int b_len,
                          double R, int maxn, int maxm, pba_result *out, uint8_t *ops, int32_t ops_cap, int32_t *nedit);
+/* The DP matrix itself, for callers that read it (seq_aligner<>::mat, get_cost / get_parent, seq_aligner.h:81,131-134;
+ * locator.cpp:86): cost[i * W + c] and parent[i * W + c] for cell (i, j) with W = 2*max_dst + 1 and c = j - i + max_dst, the
+ * reference's own diagonal-stripe layout; (len_a + 1) * W cells (cap_cells must hold them: len_a and max_dst follow from the
+ * lengths and R as in seq_aligner.h:94-102).  Cells the call writes -- init_cell's borders and the band of rows
+ * 1 .. *rows_swept (all rows, or up to the row of the early failure) -- hold their values; every other cell holds cost
+ * 0xFFFF and parent 0 (the reference would hand back whatever an earlier call left there).  One pair, raw bytes. */
+int pba_align_text_matrix(pba_ctx *ctx, const char *a, int a_fwd, int a_len, const char *b, int b_fwd, int b_len, double R,
+                          int maxn, int maxm, pba_result *out, uint16_t *cost, uint8_t *parent, uint64_t cap_cells,
+                          int32_t *rows_swept);
 /* Batch form on packed sets: pair q's script goes to ops[ops_off[q] .. ops_off[q+1]) (needs a_len + b_len
  * slots), its length to nedit[q] (0 when rc < 0).  kernel: PBA_KERNEL_AUTO / _BITVEC run the bit-vector array
  * and stream 2 parent bits per processed cell into a per-wavefront scratch area that the same wavefront walks
@@ -289,6 +300,8 @@ typedef struct {
     int32_t seglen;      /* TSV column 4: len - j */
     int32_t matlen_a, matlen_b;
     int32_t n_pairs;     /* candidate pairs the reference loop hands to align for this read */
+    int32_t diag_cost;   /* TSV column 5 (locator.cpp:86): get_cost(len - j, len - j), a written cell when the contig remainder is
+                          * at least as long as the read remainder; -1 if none */
 } pba_loc_row;
 
 typedef struct {

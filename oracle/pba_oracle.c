@@ -148,6 +148,7 @@ struct orc_aligner {
     int maxn, maxm;
     orc_cell *mat;
     size_t cap;       /* cells allocated */
+    int last_len_a, last_len_b, last_max_dst, last_rows;   /* the band of the most recent orc_align (orc_aligner_cell) */
 };
 
 /* Aligners are pooled across driver calls: like the reference's one static aligner per process
@@ -239,6 +240,20 @@ static int aligner_reserve(orc_aligner *al, size_t need)
 
 static inline char acc_at(const char *p, int fwd, int k) { return fwd ? p[k] : p[-k]; }
 
+/* seq_aligner::get_cost / get_parent (seq_aligner.h:131,133) of the most recent orc_align on this aligner: 0 and the
+ * cell's cost / parent when (i, j) is a cell that call wrote (rows 0 .. the last row swept, inside the band and the
+ * matrix: init_cell's borders included), else -1 -- the reference would hand back whatever an earlier call left there. */
+int orc_aligner_cell(const orc_aligner *al, int i, int j, int *cost, int *parent)
+{
+    const int md = al->last_max_dst;
+    if (al->last_rows < 0 || i < 0 || j < 0 || i > al->last_rows || j > al->last_len_b || j - i > md || i - j > md) return -1;
+    if (i == 0 && j > md) return -1;
+    const orc_cell *c = &al->mat[(size_t)i * (2 * (size_t)md + 1) + (size_t)(j - i + md)];
+    if (cost) *cost = c->cost;
+    if (parent) *parent = c->parent;
+    return 0;
+}
+
 int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
               const char *b, int b_fwd, int lb, double R,
               orc_result *res, uint8_t *ops)
@@ -258,6 +273,7 @@ int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
         len_a = la < len_b + max_dst ? la : len_b + max_dst;
     }
     res->len_a = len_a; res->len_b = len_b; res->max_dst = max_dst;
+    al->last_rows = -1;
 
     /* seq_aligner.h:104-107 */
     if (al->maxn > 0 && (len_a >= al->maxn + al->maxm || max_dst >= al->maxm))
@@ -267,6 +283,7 @@ int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
     const size_t need = ((size_t)len_a + 1) * W;
     if (aligner_reserve(al, need) != 0) return -1;
     orc_cell *mat = al->mat;
+    al->last_len_a = len_a; al->last_len_b = len_b; al->last_max_dst = max_dst; al->last_rows = 0;
 #define CELL(i, j) mat[(size_t)(i) * W + (size_t)((j) - (i) + max_dst)]
 
     /* init_cell, seq_aligner.h:139-150 */
@@ -293,6 +310,7 @@ int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
         cells += end >= beg ? end - beg + 1 : 0;
         /* early failure, seq_aligner.h:185; the i<=len_b guard is the canonical
          * reading of an unwritten diagonal cell */
+        al->last_rows = i;
         if (i > 10 && i <= len_b && (double)CELL(i, i).cost > i * R) {
             res->fail_row = i;
             res->cells = cells;

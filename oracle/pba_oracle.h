@@ -62,6 +62,10 @@ int orc_align(orc_aligner *al, const char *a, int a_fwd, int la,
               const char *b, int b_fwd, int lb, double R,
               orc_result *res, uint8_t *ops);
 
+/* get_cost / get_parent (seq_aligner.h:131,133) of the most recent orc_align on `al`: 0 and the values when (i, j) is a
+ * cell that call wrote, -1 otherwise (the reference returns stale memory there) */
+int orc_aligner_cell(const orc_aligner *al, int i, int j, int *cost, int *parent);
+
 /* Map and touch the DP matrices of n pooled aligners (the drivers below draw their per-thread aligners
  * from that pool) for up to len_a rows at ratio R; orc_pool_release frees them. */
 int  orc_prefault(int n, int len_a, double R);

@@ -95,6 +95,12 @@ int ref_align(char *a, int a_fwd, int la, char *b, int b_fwd, int lb, double R, 
     return run_align(big(), a, a_fwd, la, b, b_fwd, lb, R, out, ops);
 }
 
+/* seq_aligner::get_cost / get_parent (seq_aligner.h:131,133) on the canonical aligner, after the last ref_align */
+void ref_cell(int i, int j, int32_t *out) {
+    out[0] = big()->get_cost(i, j);
+    out[1] = big()->get_parent(i, j);
+}
+
 /* the stock typedef (seq_aligner<26000,6000>), canonicalised the same way */
 int ref_align_stock(char *a, int a_fwd, int la, char *b, int b_fwd, int lb, double R, int32_t *out, uint8_t *ops) {
     if (!g_stock) g_stock = new t_aligner();

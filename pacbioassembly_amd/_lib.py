@@ -20,12 +20,12 @@ class PbaPair(C.Structure):
 
 
 class PbaResult(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("rc", "cost", "matlen_a", "matlen_b", "len_a", "len_b", "max_dst")]
+    _fields_ = [(n, C.c_int32) for n in ("rc", "cost", "matlen_a", "matlen_b", "len_a", "len_b", "max_dst", "diag_cost")]
 
 
 class PbaLocRow(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("read", "nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs")]
+                ("read", "nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs", "diag_cost")]
 
 
 class PbaLocStats(C.Structure):
@@ -98,6 +98,8 @@ SYMBOLS = {
     "pba_align_text": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P]),
     "pba_align_text_trace": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P,
                                        C.c_int32, C.POINTER(C.c_int32)]),
+    "pba_align_text_matrix": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _P, _P, _P,
+                                        C.c_uint64, C.POINTER(C.c_int32)]),
     "pba_align_batch_trace": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "pba_locate": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              _P, _P]),

@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 // at tr[((t-1) * NB + nb) * 128 + 2 * lane + word]: one 8-byte store per lane, 512 contiguous bytes per instruction.
 template <int NB, bool TRACE = false>
 __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
-                                           double R, int &best_out, int &besti_out, uint32_t *tr = nullptr,
+                                           double R, int &best_out, int &besti_out, int &diag_out, uint32_t *tr = nullptr,
                                            bool swap_roles = false) {
     // rowsF / nr: the longer sequence and how many of its rows are swept (m <= nr <= m + wleft); colsF / m: the shorter
     // one.  Row i sees the columns [i - wleft, i + w] (wleft: the wide side, towards the free end; w: the narrow one).
@@ -414,6 +414,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     // them (the callers' candidate walks, and through their lengths this function's own step loop) is treated
     // as divergent and its counters and bounds move from SGPRs into VGPRs
     int gbest = __builtin_amdgcn_readlane(best, s_m & (PBA_WAVE - 1)), gi = m, run = gbest;   // D(m,m)
+    diag_out = gbest;
     for (int sb = s_m; sb < S; ++sb) {
         const int L = sb & (PBA_WAVE - 1);
 #pragma unroll
@@ -473,10 +474,12 @@ __device__ __forceinline__ bool bv_goal_certified(int best, int wl, int w, int m
 // goal row cannot be certified; the host then re-launches those pairs with full_band = true.
 // There is deliberately no device function call in here: everything inlines into the kernel.
 // lds: >= 256 bytes (only the m <= 10 corner uses it, through the row sweep)
+// need_diag: the caller reports D(m,m) (locator.cpp:86): a narrow pass whose window cannot vouch for that cell too
+// answers PBA_RC_UNCERTIFIED; without it o.diag is -1 in that case.
 template <int NB>
 __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
                                              int maxn, int maxm, bool full_band, uint16_t *lds, int lds_cells,
-                                             AlnOut &o) {
+                                             AlnOut &o, bool need_diag = false) {
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
     if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return;      // seq_aligner.h:104-107
@@ -490,14 +493,18 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
     const int w = full_band ? md : bv_pass1_w(md, NB), wl = full_band ? bv_full_wl(md) : bv_pass1_wl(md, NB);
     if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
-    int best = 0, besti = 0;
-    const int fr = bitvec_pass<NB>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti);
+    int best = 0, besti = 0, diag = 0;
+    const int fr = bitvec_pass<NB>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag);
     if (fr) {
         if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return;
     }
     if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return; }   // header comment
+    // D(m,m) is a cell like the goal cells: exact when it is small enough for its path to lie inside the windows
+    const bool diag_ok = bv_goal_certified(diag, wl, w, md);
+    if (need_diag && !diag_ok) { o.rc = PBA_RC_UNCERTIFIED; return; }
     o.cost = best;
+    o.diag = diag_ok ? diag : -1;
     o.matlen_a = a_rows ? besti : m;
     o.matlen_b = a_rows ? m : besti;
     o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114

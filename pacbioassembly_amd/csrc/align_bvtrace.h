@@ -141,15 +141,16 @@ __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la
     }
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
     const int w = full_band ? md : bv_pass1_w(md, NB), wl = full_band ? bv_full_wl(md) : bv_pass1_wl(md, NB);
-    int best = 0, besti = 0;
+    int best = 0, besti = 0, diag = 0;
     if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return false; }   // host sizes both
-    const int fr = bitvec_pass<NB, true>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, scratch, swap);
+    const int fr = bitvec_pass<NB, true>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag, scratch, swap);
     if (fr) {
         if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return false;
     }
     if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return false; }
     o.cost = best;
+    o.diag = bv_goal_certified(diag, wl, w, md) ? diag : -1;
     o.matlen_a = a_rows ? besti : m;
     o.matlen_b = a_rows ? m : besti;
     o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;   // seq_aligner.h:114

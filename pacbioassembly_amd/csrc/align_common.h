@@ -27,13 +27,14 @@ template <int NB> struct Wpb {
     static constexpr int occ = NB == 0 ? 1 : (NB <= 4 ? 6 : 3);   // measured on configs[1]: 5 -> 123 ms, 6 -> 105 ms, 8 (spills in the step loop) -> 113 ms
 };
 
+// need_diag: the caller reports D(m,m), the end of the diagonal (pba_result::diag_cost, locator.cpp:86)
 template <int NB>
 __device__ __forceinline__ void align_dispatch(const PackedFetch &fa, int la, const PackedFetch &fb, int lb,
-                                               const AlignCfg &cfg, void *lds, AlnOut &o) {
+                                               const AlignCfg &cfg, void *lds, AlnOut &o, bool need_diag = false) {
     if constexpr (NB == 0)
         align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o);
     else
-        align_bitvec<NB>(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds, cfg.row_cap, o);
+        align_bitvec<NB>(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds, cfg.row_cap, o, need_diag);
 }
 
 __device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
@@ -44,6 +45,7 @@ __device__ __forceinline__ void store_result(pba_result *out, const AlnOut &o) {
         out->matlen_a = ok ? o.matlen_a : 0;
         out->matlen_b = ok ? o.matlen_b : 0;
         out->len_a = o.len_a; out->len_b = o.len_b; out->max_dst = o.max_dst;
+        out->diag_cost = o.diag;
     }
 }
 

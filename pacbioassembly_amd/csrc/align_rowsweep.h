@@ -27,9 +27,11 @@ __device__ __forceinline__ int wave_prefix_min(int y, int lane) {
 
 // par (nullable): one parent code per band cell (seq_aligner.h:165-175: 1 MATCH, 2 INSERT, 3 DELETE) at
 // par[i * (2*max_dst+1) + (j - i + max_dst)], for the traceback of seq_aligner.h:214-233.
+// cst (nullable, needs par): the cell's cost at the same index -- the reference's `mat` (seq_aligner.h:81,131-134) for the
+// callers that read it (pba_align_text_matrix); rows 1.., column 0 included (init_cell's DELETE border), row 0 is the host's.
 template <class FA, class FB>
 __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, double R, int maxn, int maxm,
-                               uint16_t *row, int row_cap, AlnOut &o, uint8_t *par = nullptr) {
+                               uint16_t *row, int row_cap, AlnOut &o, uint8_t *par = nullptr, uint16_t *cst = nullptr) {
     const int lane = threadIdx.x & (PBA_WAVE - 1);
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, m = o.max_dst;
@@ -76,6 +78,10 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
                 if (c > 0 && left + 1 < cost) { cost = left + 1; src = 2; }   // i-j < max_dst  <=>  c > 0
                 if (vd < cost) src = 3;                                       // j-i < max_dst is in vd (INF otherwise)
                 if (inb && j > 0) par[(size_t)i * W + c] = (uint8_t)src;
+                if (cst && inb) {
+                    cst[(size_t)i * W + c] = (uint16_t)min(nv, 0xFFFF);
+                    if (j == 0) par[(size_t)i * W + c] = 3;       // set_parent(i, 0, DELETE), seq_aligner.h:142
+                }
             }
             carry = __builtin_amdgcn_readlane(nv, PBA_WAVE - 1);
             __builtin_amdgcn_wave_barrier();
@@ -87,6 +93,7 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
             const int d = __builtin_amdgcn_readfirstlane((int)row[m]);
             if ((double)d > (double)i * R) { o.fail_row = i; return; }
         }
+        if (i == min(len_a, len_b)) o.diag = __builtin_amdgcn_readfirstlane((int)row[m]);   // D(i,i), the end of the diagonal
         if (len_a > len_b && i >= len_b) {              // goal_cell, seq_aligner.h:192-201
             const int v = __builtin_amdgcn_readfirstlane((int)row[len_b - i + m]);
             if (i == len_b || v < col_best) { col_best = v; col_ml = i; }

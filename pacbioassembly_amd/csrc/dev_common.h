@@ -72,6 +72,7 @@ struct ByteFetch {
 // what one alignment produces (seq_aligner.h:73-81 plus the early-failure row)
 struct AlnOut {
     int rc, cost, matlen_a, matlen_b, len_a, len_b, max_dst, fail_row;
+    int diag;      // D(m, m), m = min(len_a, len_b): the end of the diagonal (locator.cpp:86 prints it); -1 unless the sweep got there
 };
 
 // parameter block of seq_aligner::align, seq_aligner.h:94-102.  The products are formed in
@@ -88,6 +89,7 @@ __device__ __forceinline__ void aln_params(int la, int lb, double R, AlnOut &o) 
     }
     o.rc = -1;
     o.cost = o.matlen_a = o.matlen_b = o.fail_row = 0;
+    o.diag = -1;
 }
 
 // band cells the reference sweep evaluates in rows 1..n (seq_aligner.h:158-161), closed form

@@ -410,6 +410,9 @@ k_ovl_items(const uint32_t *item_pre, const uint32_t *cand_off, uint32_t n_targe
     items[i] = make_uint2(lo, cand_off[lo] + (i - item_pre[lo]) * PBA_WAVE);
 }
 
+#define PBA_OVL_CHUNK 16          // work items a wavefront takes at a time (big inputs)
+#define PBA_OVL_S2_CAP 256        // survivors of the first prefilter stage a chunk can hand to the second
+
 struct OvlCfg {
     double R;
     int overlap_min;
@@ -476,17 +479,68 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
     uint16_t *lds = (uint16_t *)(lds_all + (size_t)wave * cfg.row_cap * 2);
     const bool l0 = (threadIdx.x & (PBA_WAVE - 1)) == 0;
+    const uint32_t lane_id = threadIdx.x & (PBA_WAVE - 1);
     const PreThresholds pre_t(cfg.R);
     // A million reads make hundreds of millions of light items (a group of 64 mostly false candidates): one atomic on
     // the queue and one on the pair counter per item is then what the walk waits for (every wavefront on the same two
-    // addresses).  Items are taken 16 at a time there and the pairs are added up per wavefront.
-    const uint32_t chunk = (redo_in || n_items < (1u << 20)) ? 1u : 16u;
+    // addresses).  Items are taken up to 16 at a time and the pairs are added up per wavefront.
+    const uint32_t chunk = redo_in ? 1u : (n_items >= (1u << 17) ? (uint32_t)PBA_OVL_CHUNK : (n_items >= (1u << 14) ? 4u : 1u));
+    // Two-stage prefilter over a chunk (first launch, bit-vector kernels): the first 32 rows of every candidate of the
+    // chunk's groups (one candidate per lane, prefilter32), the survivors of ALL its groups listed in LDS and put
+    // through rows 33..64 together (prefilter64, one survivor per lane) -- and only what passes both reaches the
+    // wavefront-wide array.  fail[k]: lanes of group k that failed in either stage.
+    constexpr int WPB = NB ? 4 : 1;
+    __shared__ uint32_t s2_fail[WPB][PBA_OVL_CHUNK][2];
+    __shared__ uint16_t s2_list[WPB][PBA_OVL_S2_CAP];
+    const bool two_stage = NB != 0 && !redo_in;
     unsigned long long pairs = 0;
     for (;;) {
         const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
             (int)atomicAdd(queue, l0 ? chunk : 0u));                    // see next_slot() in pba_device.hip
         if (base >= n_items) break;
         const uint32_t item_end = min(n_items, base + chunk);
+        if constexpr (NB != 0) {
+          if (two_stage) {
+            uint32_t ns = 0;                                            // survivors of stage 1 listed so far (wave-uniform)
+            for (uint32_t k = 0; k < item_end - base; ++k) {
+                const uint2 it = items[base + k];
+                const uint32_t c_end_k = cand_off[it.x] + cand_cnt[it.x];
+                const bool act = lane_id < min((uint32_t)PBA_WAVE, c_end_k - it.y);
+                const uint64_t cd = act ? cand[it.y + lane_id] : 0ull;
+                const uint32_t t = t_lo + it.x;
+                const int ref_len = (int)Rd.len[t];
+                const HeadTail ht(ref_len);
+                const OvlCand m = ovl_decode(Rd, ref_len, ht, cd, cfg);
+                AlnOut po;
+                const int fr = prefilter32(act && m.ok, fetch_of(Rd, t, m.r_off, m.fwd ? 1 : -1), m.r_len,
+                                           fetch_of(Rd, act ? m.q : 0u, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R, 0, 0, pre_t, po);
+                const uint64_t f1 = __builtin_amdgcn_ballot_w64(fr != 0);
+                const uint64_t s1 = __builtin_amdgcn_ballot_w64(act && m.ok && fr == 0);
+                if (l0) { s2_fail[wave][k][0] = (uint32_t)f1; s2_fail[wave][k][1] = (uint32_t)(f1 >> 32); }
+                if (s1) {
+                    const uint32_t at = ns + (uint32_t)__builtin_popcountll(s1 & ((1ull << lane_id) - 1ull));
+                    if (((s1 >> lane_id) & 1ull) && at < PBA_OVL_S2_CAP) s2_list[wave][at] = (uint16_t)(k << 6 | lane_id);
+                    ns += (uint32_t)__builtin_popcountll(s1);
+                }
+            }
+            ns = min(ns, (uint32_t)PBA_OVL_S2_CAP);                     // (survivors beyond the list go to the array untested: still exact)
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t b0 = 0; b0 < ns; b0 += PBA_WAVE) {
+                const bool have = b0 + lane_id < ns;
+                const uint32_t e = have ? s2_list[wave][b0 + lane_id] : 0u, k = e >> 6, ln = e & 63u;
+                const uint2 it = items[base + (have ? k : 0u)];
+                const uint64_t cd = have ? cand[it.y + ln] : 0ull;
+                const uint32_t t = t_lo + it.x;
+                const int ref_len = (int)Rd.len[t];
+                const HeadTail ht(ref_len);
+                const OvlCand m = ovl_decode(Rd, ref_len, ht, cd, cfg);
+                const bool fail2 = prefilter64(have, fetch_of(Rd, t, m.r_off, m.fwd ? 1 : -1), m.r_len,
+                                               fetch_of(Rd, have ? m.q : 0u, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R);
+                if (fail2) atomicOr(&s2_fail[wave][k][ln >> 5], 1u << (ln & 31u));
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
         for (uint32_t item = base; item < item_end; ++item) {
         const uint32_t NONE = 0xFFFFFFFFu;
         uint32_t tl, c_begin, c_end, own_end, skip_q = NONE, only_q = NONE;
@@ -518,9 +572,14 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             const OvlCand m = ovl_decode(Rd, ref_len, ht, mycd, cfg);
             int myfr = 0;
             if constexpr (NB != 0) {
-                AlnOut po;
-                myfr = prefilter32(act && m.ok, ref.at(m.r_off, m.fwd ? 1 : -1), m.r_len,
-                                   fetch_of(Rd, act ? myq : 0u, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R, 0, 0, pre_t, po);
+                if (two_stage && c0 == c_begin) {                        // both stages ran on this group with the rest of the chunk
+                    const uint32_t w32 = s2_fail[wave][item - base][lane >> 5];
+                    myfr = (int)((w32 >> (lane & 31u)) & 1u);
+                } else {
+                    AlnOut po;
+                    myfr = prefilter32(act && m.ok, ref.at(m.r_off, m.fwd ? 1 : -1), m.r_len,
+                                       fetch_of(Rd, act ? myq : 0u, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R, 0, 0, pre_t, po);
+                }
             }
             // Nearly every candidate has failed by now, so the group is not walked lane by lane: lane masks say where the
             // walk of this group ends, which failed candidates count as pairs, and only the survivors are visited.

@@ -20,7 +20,7 @@ k_align_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *i
         const PackedFetch fa = fetch_of(A, pr.a_seq, pr.a_pos, (pr.flags & PBA_A_BACKWARD) ? -1 : 1);
         const PackedFetch fb = fetch_of(B, pr.b_seq, pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1);
         AlnOut o;
-        align_dispatch<NB>(fa, pr.a_len, fb, pr.b_len, cfg, lds, o);
+        align_dispatch<NB>(fa, pr.a_len, fb, pr.b_len, cfg, lds, o, true);
         store_result(out + q, o);
     }
 }
@@ -52,11 +52,11 @@ k_align_pairs_trace(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, uint32_t n,
 
 __global__ void __launch_bounds__(PBA_WAVE)
 k_align_bytes_trace(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b_dir, int lb, AlignCfg cfg,
-                    pba_result *out, uint8_t *par) {
+                    pba_result *out, uint8_t *par, uint16_t *cst) {
     extern __shared__ __align__(16) uint8_t lds[];
     ByteFetch fa{a, a_dir}, fb{b, b_dir};
     AlnOut o;
-    align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o, par);
+    align_rowsweep(fa, la, fb, lb, cfg.R, cfg.maxn, cfg.maxm, (uint16_t *)lds, cfg.row_cap, o, par, cst);
     store_result(out, o);
 }
 
@@ -286,7 +286,7 @@ int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int la, const c
     const uint8_t *da = buf.as<uint8_t>() + oa + (a_fwd || !la ? 0 : la - 1);
     const uint8_t *db = buf.as<uint8_t>() + ob + (b_fwd || !lb ? 0 : lb - 1);
     hipLaunchKernelGGL(k_align_bytes_trace, dim3(1), dim3(PBA_WAVE), pl.lds, ctx->stream, da, a_fwd ? 1 : -1, la, db,
-                       b_fwd ? 1 : -1, lb, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>());
+                       b_fwd ? 1 : -1, lb, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>(), (uint16_t *)nullptr);
     hipLaunchKernelGGL(k_trace_walk, dim3(1), dim3(64), 0, ctx->stream, d_out.as<pba_result>(), d_par.as<uint8_t>(),
                        d_off.as<uint64_t>() + 2, d_ops.as<uint8_t>(), d_off.as<uint64_t>(), d_ne.as<int32_t>(), 1u);
     HIPCHK(hipGetLastError());
@@ -296,6 +296,58 @@ int pba_align_text_trace(pba_ctx *ctx, const char *a, int a_fwd, int la, const c
     const int32_t ncopy = std::min(*nedit, ops_cap);
     if (ncopy > 0) HIPCHK(hipMemcpyAsync(ops, d_ops.p, (size_t)ncopy, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PBA_OK;
+}
+
+// The reference's DP matrix of one pair (seq_aligner.h:81 `mat`, read through get_cost / get_parent :131-134 by
+// locator.cpp:86 and by whoever inspects an alignment): cost[i * W + c] / parent[i * W + c] for cell (i, j), W = 2*max_dst+1,
+// c = j - i + max_dst -- the reference's own diagonal-stripe layout.  Cells the call writes hold their values (init_cell's
+// borders, the band of every row swept: all of them, or up to the row of the early failure, out->diag_cost / rc tell which);
+// the others hold cost 0xFFFF, parent 0 (the reference leaves whatever an earlier call wrote there).
+int pba_align_text_matrix(pba_ctx *ctx, const char *a, int a_fwd, int la, const char *b, int b_fwd, int lb, double R, int maxn,
+                          int maxm, pba_result *out, uint16_t *cost, uint8_t *parent, uint64_t cap_cells, int32_t *rows_swept) {
+    if (!ctx || !out || la < 0 || lb < 0 || (!a && la) || (!b && lb) || ((!cost || !parent) && cap_cells)) return PBA_E_INVALID;
+    if (la > kMaxSeqLen || lb > kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "pba_align_text_matrix");
+    HIPCHK(hipSetDevice(ctx->device));
+    tu_attrs();
+    Plan pl;
+    int st = make_plan(ctx, R, maxn, maxm, PBA_KERNEL_ROWSWEEP, max_dst_of(la, lb, R), &pl);
+    if (st != PBA_OK) return st;
+    const int md = max_dst_of(la, lb, R);
+    const uint64_t pb = par_bytes_of(la, lb, R);                  // cells: (len_a + 1) * (2*max_dst + 1)
+    if (pb * 3 > kTraceBudget) PBA_FAIL(PBA_E_NOMEM, "the matrix exceeds the traceback budget");
+    if (cap_cells < pb) PBA_FAIL(PBA_E_INVALID, "pba_align_text_matrix: cost / parent hold fewer than (len_a + 1) * (2*max_dst + 1) cells");
+    const size_t oa = 0, ob = ((size_t)la + 31) & ~(size_t)15;
+    DevBuf buf, d_out, d_par, d_cst;
+    HIPCHK(hipMalloc(&buf.p, ob + lb + 32));
+    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_result)));
+    HIPCHK(hipMalloc(&d_par.p, pb + 16));
+    HIPCHK(hipMalloc(&d_cst.p, 2 * pb + 16));
+    HIPCHK(hipMemsetAsync(d_par.p, 0, pb, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_cst.p, 0xFF, 2 * pb, ctx->stream));
+    if (la) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + oa, a_fwd ? a : a - (la - 1), la, hipMemcpyHostToDevice, ctx->stream));
+    if (lb) HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + ob, b_fwd ? b : b - (lb - 1), lb, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *da = buf.as<uint8_t>() + oa + (a_fwd || !la ? 0 : la - 1);
+    const uint8_t *db = buf.as<uint8_t>() + ob + (b_fwd || !lb ? 0 : lb - 1);
+    hipLaunchKernelGGL(k_align_bytes_trace, dim3(1), dim3(PBA_WAVE), pl.lds, ctx->stream, da, a_fwd ? 1 : -1, la, db,
+                       b_fwd ? 1 : -1, lb, pl.cfg, d_out.as<pba_result>(), d_par.as<uint8_t>(), d_cst.as<uint16_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(cost, d_cst.p, 2 * pb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(parent, d_par.p, pb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // init_cell (seq_aligner.h:139-150): row 0 is D(0,j) = j, INSERT, for j <= max_dst; the size guard leaves everything unwritten
+    const uint64_t W = 2ull * md + 1;
+    int swept = 0;
+    if (!(maxn > 0 && (out->len_a >= maxn + maxm || md >= maxm))) {
+        for (int j = 0; j <= md; ++j) { cost[(uint64_t)md + j] = (uint16_t)j; parent[(uint64_t)md + j] = j ? 2 : 0; }
+        // rows swept: every row up to len_a, or up to the early failure -- the last row whose diagonal-side cell was written
+        for (swept = out->len_a; swept > 0; --swept) {
+            const int jlo = swept - md > 0 ? swept - md : 0;
+            if (cost[(uint64_t)swept * W + (uint64_t)(jlo - swept + md)] != 0xFFFF) break;
+        }
+    }
+    if (rows_swept) *rows_swept = swept;
     return PBA_OK;
 }
 

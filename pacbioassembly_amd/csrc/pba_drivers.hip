@@ -33,7 +33,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
     if (slot >= n) break;
     const uint32_t r = ids ? ids[slot] : slot;
     const int len = (int)Rd.len[r];
-    int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, npairs = 0, nhit = 0, redo = 0;
+    int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, fdiag = -1, npairs = 0, nhit = 0, redo = 0;
     long long ncell = 0;
     if (len >= min_len) {                                                   // locator.cpp:72
         const PackedFetch rbase = fetch_of(Rd, r, 0, 1), tbase = fetch_of(T, tseq, 0, 1);
@@ -72,12 +72,12 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
                     const PackedFetch fa = rbase.at(j, 1);                  // a = read from j   (locator.cpp:78)
                     const PackedFetch fb = tbase.at(pos, 1);                // b = contig from pos (locator.cpp:80)
                     AlnOut o;
-                    align_dispatch<NB>(fa, len - j, fb, clen - pos, cfg, lds, o);
+                    align_dispatch<NB>(fa, len - j, fb, clen - pos, cfg, lds, o, true);
                     if (o.rc == PBA_RC_UNCERTIFIED) { redo = 1; break; }
                     ++npairs;
                     ncell += pair_cells(o);
                     if (o.rc > 0) {                                         // locator.cpp:82
-                        found = 1; fj = j; fpos = pos; fcost = o.cost; fma = o.matlen_a; fmb = o.matlen_b;
+                        found = 1; fj = j; fpos = pos; fcost = o.cost; fma = o.matlen_a; fmb = o.matlen_b; fdiag = o.diag;
                         break;
                     }
                 }
@@ -88,6 +88,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
         pba_loc_row *row = rows + r;          // read / nseq are filled by the host
         row->found = found; row->j = fj; row->pos = fpos; row->cost = fcost;
         row->seglen = found ? len - fj : 0; row->matlen_a = fma; row->matlen_b = fmb; row->n_pairs = npairs;
+        row->diag_cost = fdiag;
         aux[r].cells = ncell; aux[r].probe_hits = nhit; aux[r].redo = redo;
     }
     }

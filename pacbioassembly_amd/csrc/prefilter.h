@@ -70,4 +70,60 @@ __device__ __forceinline__ int prefilter32(bool active, const PackedFetch &fa, i
     return prefilter32_planes(alo, ahi, blo, bhi, T);
 }
 
+// ---- second stage: rows 33..64, still one pair per lane
+// About one random pair in seventy survives its first 32 rows; nearly all of those fail before row 64.  Handing each
+// of them to the wavefront-wide array costs ~2 500 instructions a piece (one pair in flight, the array mostly in its
+// ramp); the same 64 rows as a two-block Myers column sweep in ONE lane cost about as much for up to 64 survivors at
+// once.  Callers collect the survivors of many groups and run this on them together.  Same exactness argument as
+// above: cell (i,i), i <= 64, depends on the square [1..i] x [1..i] only.
+#define PBA_PRE2_ROWS 64
+// true: some row 11..64 fails the reference's check (seq_aligner.h:185); false: all pass, or the stage does not apply
+// (a sequence shorter than 64 after clipping) and the full aligner decides
+__device__ __forceinline__ bool prefilter64(bool active, const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R) {
+    AlnOut o;
+    aln_params(la, lb, R, o);
+    if (!active || o.len_a < PBA_PRE2_ROWS || o.len_b < PBA_PRE2_ROWS) return false;
+    uint32_t alo[2], ahi[2], blo[2], bhi[2];
+    load_planes32(fa, 0, alo[0], ahi[0]);
+    load_planes32(fa, 32, alo[1], ahi[1]);
+    load_planes32(fb, 0, blo[0], bhi[0]);
+    load_planes32(fb, 32, blo[1], bhi[1]);
+    uint32_t Pv0 = ~0u, Mv0 = 0u, Pv1 = ~0u, Mv1 = 0u;
+    int score = 0;                              // D(k, k)
+    bool failed = false;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 4
+        for (int kk = 0; kk < 32; ++kk) {
+            const int k = 32 * half + kk;
+            const uint32_t clo = bit_mask(blo[half], kk), chi = bit_mask(bhi[half], kk);
+            // rows 1..32
+            const uint32_t Eq0 = ~(alo[0] ^ clo) & ~(ahi[0] ^ chi);
+            const uint32_t Xv0 = Eq0 | Mv0;
+            const uint32_t Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
+            uint32_t Ph0 = Mv0 | ~(Xh0 | Pv0), Mh0 = Pv0 & Xh0;
+            const uint32_t D00 = Xh0 | Mv0;     // bit r: D(r+1, k+1) == D(r, k)
+            const uint32_t hp = Ph0 >> 31, hm = Mh0 >> 31;                   // the delta leaving row 32
+            Ph0 = (Ph0 << 1) | 1u;              // row 0 grows by one per column: D(0,j) = j
+            Mh0 <<= 1;
+            Pv0 = Mh0 | ~(Xv0 | Ph0);
+            Mv0 = Ph0 & Xv0;
+            // rows 33..64, the delta of row 32 coming in at the top
+            const uint32_t Eq1 = ~(alo[1] ^ clo) & ~(ahi[1] ^ chi);
+            const uint32_t Xv1 = Eq1 | Mv1;
+            const uint32_t Eq1c = Eq1 | hm;
+            const uint32_t Xh1 = (((Eq1c & Pv1) + Pv1) ^ Pv1) | Eq1c;
+            uint32_t Ph1 = Mv1 | ~(Xh1 | Pv1), Mh1 = Pv1 & Xh1;
+            const uint32_t D01 = Xh1 | Mv1;
+            Ph1 = (Ph1 << 1) | hp;
+            Mh1 = (Mh1 << 1) | hm;
+            Pv1 = Mh1 | ~(Xv1 | Ph1);
+            Mv1 = Ph1 & Xv1;
+            score += 1 - (int)(((half ? D01 : D00) >> kk) & 1u);             // D(k+1, k+1)
+            if (k + 1 > 10 && (double)score > (double)(k + 1) * R) failed = true;   // seq_aligner.h:185, FP64 like the reference
+        }
+    }
+    return failed;
+}
+
 #endif

@@ -17,9 +17,9 @@ from ._lib import (PBA_INDEX_ALL, PBA_INDEX_HEAD_TAIL, PBA_KERNEL_AUTO, PBA_KERN
 
 PAIR_DTYPE = np.dtype([("a_seq", "<u4"), ("a_pos", "<i4"), ("a_len", "<i4"), ("b_seq", "<u4"), ("b_pos", "<i4"),
                        ("b_len", "<i4"), ("flags", "<u4")])
-RESULT_DTYPE = np.dtype([(n, "<i4") for n in ("rc", "cost", "matlen_a", "matlen_b", "len_a", "len_b", "max_dst")])
+RESULT_DTYPE = np.dtype([(n, "<i4") for n in ("rc", "cost", "matlen_a", "matlen_b", "len_a", "len_b", "max_dst", "diag_cost")])
 LOC_ROW_DTYPE = np.dtype([(n, "<i4") for n in
-                          ("read", "nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs")])
+                          ("read", "nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs", "diag_cost")])
 SS_ROW_DTYPE = np.dtype([(n, "<i4") for n in
                          ("read", "found", "j", "dir", "ref_pos", "cost", "matlen_a", "matlen_b", "n_trials",
                           "n_pairs")])
@@ -261,6 +261,25 @@ class Context:
         self.check(self.lib.pba_align_text_trace(self.h, C.c_void_p(pa), int(a_fwd), len(a), C.c_void_p(pb), int(b_fwd), len(b),
                                                  R, maxn, maxm, _ptr(out), _ptr(ops), cap, C.byref(ne)), "align_text_trace")
         return out[0], ops[:ne.value].copy()
+
+    def align_text_matrix(self, a: bytes, b: bytes, R: float, a_fwd: bool = True, b_fwd: bool = True, maxn: int = 0, maxm: int = 0):
+        """The DP matrix of one pair (pba_align_text_matrix): returns (result, cost uint16[len_a+1, 2*max_dst+1], parent
+        uint8[same], rows swept); cell (i, j) sits at [i, j - i + max_dst]."""
+        abuf = np.frombuffer(a + b"\0", np.uint8)
+        bbuf = np.frombuffer(b + b"\0", np.uint8)
+        pa = abuf.ctypes.data + (0 if a_fwd or not a else len(a) - 1)
+        pb = bbuf.ctypes.data + (0 if b_fwd or not b else len(b) - 1)
+        la, lb = len(a), len(b)
+        md = 1 + int((la if lb >= la else lb) * R)
+        len_a = la if lb >= la else min(la, lb + md)
+        W = 2 * md + 1
+        cost = np.zeros((len_a + 1, W), np.uint16)
+        par = np.zeros((len_a + 1, W), np.uint8)
+        out = np.zeros(1, RESULT_DTYPE)
+        rows = C.c_int32()
+        self.check(self.lib.pba_align_text_matrix(self.h, C.c_void_p(pa), int(a_fwd), la, C.c_void_p(pb), int(b_fwd), lb, R, maxn, maxm,
+                                                  _ptr(out), _ptr(cost), _ptr(par), cost.size, C.byref(rows)), "align_text_matrix")
+        return out[0], cost, par, rows.value
 
     def align_batch_trace(self, A: "SeqSet", B: "SeqSet", pairs: np.ndarray, R: float, maxn: int = 0, maxm: int = 0,
                           kernel: int = PBA_KERNEL_AUTO):

@@ -99,6 +99,37 @@ static void aligner(const char *real_align_path) {   // test/aligner_test.cpp:44
         seq_accessor seg2((char *)seg_str.c_str(), true, seg_str.length());
         CHECK(-1 == pal->align(&seg2, &ref2));
     }
+    {   // the matrix behind the alignment: get_cost / get_parent / set_cost / set_parent / mat (seq_aligner.h:81,131-134)
+        // a = "ACGTAACC" vs b = "ACGAACCGG": D(i,j) by hand; max_dst = 1 + (int)(8 * 0.3) = 3
+        char a[] = "ACGTAACC", b[] = "ACGAACCGG";
+        seq_accessor sa(a, true, 8), sb(b, true, 9);
+        int rc = pal->align(&sa, &sb);
+        CHECK(rc > 0 && pal->len_a == 8 && pal->len_b == 9 && pal->max_dst == 3);
+        CHECK(pal->final_cost() == pal->get_cost(pal->matlen_a, pal->matlen_b));
+        CHECK(pal->get_cost(8, 8) == 2);                 // the end of the diagonal, what locator.cpp:86 prints (ACGTAACC vs ACGAACCG)
+        CHECK(pal->get_cost(0, 0) == 0 && pal->get_cost(0, 3) == 3 && pal->get_cost(2, 0) == 2);   // init_cell
+        CHECK(pal->get_parent(0, 2) == INSERT && pal->get_parent(3, 0) == DELETE && pal->get_parent(0, 0) == 0);
+        CHECK(pal->get_cost(3, 3) == 0 && pal->get_parent(3, 3) == MATCH);      // ACG vs ACG
+        CHECK(pal->get_cost(4, 3) == 1 && pal->get_parent(4, 3) == DELETE);     // ACGT vs ACG
+        CHECK(pal->get_cost(4, 4) == 1 && pal->get_parent(4, 4) == MATCH);      // T / A: a substitution is a MATCH op with cost
+        CHECK(pal->get_cost(5, 4) == 1 && pal->get_parent(5, 4) == MATCH);      // ACGTA vs ACGA
+        CHECK(pal->mat[5][4 - 5 + pal->max_dst].cost == 1);                     // the public array, stripe coordinates
+        pal->set_cost(5, 4, 41); pal->set_parent(5, 4, INSERT);
+        CHECK(pal->get_cost(5, 4) == 41 && pal->get_parent(5, 4) == INSERT && pal->mat[5][2].cost == 41);
+        // walking parents from the goal reproduces edits[]
+        int i = pal->matlen_a, j = pal->matlen_b, n = 0;
+        pal->set_cost(5, 4, 1); pal->set_parent(5, 4, MATCH);
+        while (i > 0 || j > 0) {
+            int p = pal->get_parent(i, j);
+            CHECK(p == (int)pal->edits[pal->nedit - 1 - n].op);
+            if (p == MATCH) { --i; --j; } else if (p == INSERT) --j; else if (p == DELETE) --i; else break;
+            ++n;
+        }
+        CHECK(n == pal->nedit);
+        // a new align() starts a new matrix
+        seq_accessor sc(a, true, 8), sd(a, true, 8);
+        CHECK(8 == pal->align(&sc, &sd) && pal->get_cost(8, 8) == 0 && pal->get_cost(5, 4) == 1 && pal->get_parent(5, 4) == DELETE);
+    }
     {   // size guard, seq_aligner.h:104-107
         seq_aligner<100, 30> small(0.3);
         std::string a(120, 'A');

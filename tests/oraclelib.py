@@ -62,6 +62,8 @@ class Oracle:
         L.orc_aligner_free.argtypes = [_P]
         L.orc_align.restype = C.c_int
         L.orc_align.argtypes = [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.POINTER(OrcResult), _P]
+        L.orc_aligner_cell.restype = C.c_int
+        L.orc_aligner_cell.argtypes = [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_seedmap_new.restype = _P; L.orc_seedmap_new.argtypes = [C.c_size_t]
         L.orc_seedmap_free.argtypes = [_P]
         L.orc_seedmap_size.restype = C.c_size_t; L.orc_seedmap_size.argtypes = [_P]
@@ -153,6 +155,13 @@ class Oracle:
         if want_ops:
             d["ops"] = ops[:res.nedit].copy() if res.rc >= 0 else ops[:0]
         return d
+
+    def cell(self, i: int, j: int):
+        """(cost, parent) of cell (i, j) as the most recent align() left it (seq_aligner.h:131,133), None if not written."""
+        c, p = C.c_int(), C.c_int()
+        if self.lib.orc_aligner_cell(self._aligner, i, j, C.byref(c), C.byref(p)) != 0:
+            return None
+        return c.value, p.value
 
     # index
     def index(self, text: bytes, mask: int, mode: str = "all"):
@@ -377,6 +386,12 @@ class Ref:
         if want_ops:
             d["ops"] = ops[:d["nedit"]].copy()
         return d
+
+    def cell(self, i: int, j: int):
+        """seq_aligner::get_cost / get_parent of the reference's aligner after the last align()."""
+        out = np.zeros(2, np.int32)
+        self.lib.ref_cell(i, j, _ptr(out))
+        return int(out[0]), int(out[1])
 
     def get_seedmap(self, text: bytes, mask: int):
         cap = len(text) + 16

@@ -618,6 +618,61 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     assert [tuple(int(x) for x in r) for r in got3] == want and st3["n_pairs"] == st["n_pairs"]
 
 
+def test_matrix_cells_and_diagonal_end_vs_oracle(ctx, oracle):
+    """seq_aligner::get_cost / get_parent (seq_aligner.h:131-134; locator.cpp:86 prints get_cost(len - j, len - j)):
+    pba_align_text_matrix returns every cell the reference's call writes -- borders, the band of every row swept, up to
+    an early failure -- with the oracle's cost and parent (which tests/test_oracle_vs_ref.py pins to the reference's own
+    array), everything else unwritten; and pba_result::diag_cost is the cell at the end of the diagonal in both kernels."""
+    rng = np.random.RandomState(77)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seqs_a, seqs_b = [], []
+    for t in range(36):
+        la = int(rng.randint(12, 420))
+        a = alpha[rng.randint(0, 4, la)]
+        e = float(rng.choice([0.05, 0.2, 0.5]))
+        b = a[rng.rand(la) > e / 2].copy()
+        flip = rng.rand(b.size) < e / 2
+        b[flip] = alpha[rng.randint(0, 4, int(flip.sum()))]
+        b = np.concatenate([b, alpha[rng.randint(0, 4, int(rng.choice([0, 7, 90])))]])
+        if t % 3 == 0:
+            a, b = b, a
+        seqs_a.append(a.tobytes()); seqs_b.append(b.tobytes())
+    n_failed = 0
+    for t, (a, b) in enumerate(zip(seqs_a, seqs_b)):
+        fwd = bool(t % 2)
+        x = oracle.align(a, b, 0.3, fwd, fwd)
+        res, cost, par, rows = ctx.align_text_matrix(a, b, 0.3, fwd, fwd)
+        assert int(res["rc"]) == x["rc"] and rows == (x["fail_row"] or x["len_a"])
+        n_failed += bool(x["fail_row"])
+        md = x["max_dst"]
+        written = np.zeros(cost.shape, bool)
+        for i in range(0, rows + 1):
+            for j in range(max(0, i - md), min(x["len_b"], i + md) + 1):
+                if i == 0 and j > md:
+                    continue
+                assert (int(cost[i, j - i + md]), int(par[i, j - i + md])) == oracle.cell(i, j), (t, i, j)
+                written[i, j - i + md] = True
+        assert (cost[~written] == 0xFFFF).all() and (par[~written] == 0).all()
+        m = min(x["len_a"], x["len_b"])
+        assert int(res["diag_cost"]) == (oracle.cell(m, m)[0] if not x["fail_row"] else -1)
+    assert 3 < n_failed < 30
+    # the batch kernels report the same cell
+    A = ctx.seqs_from_list(seqs_a, strict_acgt=True)
+    B = ctx.seqs_from_list(seqs_b, strict_acgt=True)
+    pairs = np.zeros(len(seqs_a), PAIR_DTYPE)
+    pairs["a_seq"] = pairs["b_seq"] = np.arange(len(seqs_a))
+    pairs["a_len"] = [len(s) for s in seqs_a]; pairs["b_len"] = [len(s) for s in seqs_b]
+    for kernel in KERNELS:
+        out = ctx.align_batch(A, B, pairs, 0.3, kernel=kernel)
+        for t, (a, b) in enumerate(zip(seqs_a, seqs_b)):
+            x = oracle.align(a, b, 0.3)
+            m = min(x["len_a"], x["len_b"])
+            if not x["fail_row"] and m > 10:
+                assert int(out["diag_cost"][t]) == oracle.cell(m, m)[0], (kernel, t)
+            elif x["fail_row"]:
+                assert int(out["diag_cost"][t]) == -1, (kernel, t)
+
+
 def test_read_shards_exported_and_regathered_give_the_same_overlaps(ctx):
     """The multi-GPU read exchange in one process: three "ranks" pack their shards (one of them from a binary read file,
     whose payloads are not 16-byte aligned), export the packed arenas into one padded buffer -- what the RCCL all-gather of
@@ -1077,7 +1132,38 @@ def test_locator_gpu_example_prints_what_the_reference_locator_prints(lib, tmp_p
     r = subprocess.run([exe, str(cf), LOCATOR_CLI["pattern"]], input=b"\n".join(texts) + b"\n", capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     rows = [[int(x) for x in line.split()] for line in r.stdout.decode().splitlines()]
-    assert rows == gold["rows"] and len(rows) > 250
+    assert [x[:4] for x in rows] == gold["rows"] and len(rows) > 250
+    assert [x[4] for x in rows] == gold["col5"] and min(gold["col5"]) >= 0      # get_cost(len - j, len - j), locator.cpp:86
+
+
+def test_reference_mains_linked_against_compat_print_what_they_print_on_the_cpu(lib, tmp_path):
+    """The drop-in claim itself: the reference's own locator.cpp and spaced_seed.cpp, UNMODIFIED, compiled against
+    include/compat/ instead of its src/ headers and linked with libpba.so (oracle/Makefile: locator_compat,
+    spaced_seed_compat -- built in the container where /root/reference lies, the binaries travel like the other checkers)
+    print on the GPU what the same sources print with their own headers on the CPU: all five TSV columns of locator, the
+    consensus after every round / the found lines / the dump file of spaced_seed."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from cons_scenarios import LOCATOR_CLI, locator_cli_inputs, run_spaced_seed_cli
+    exe = os.path.join(ROOT, "oracle", "_ref", "locator_compat")
+    exe2 = os.path.join(ROOT, "oracle", "_ref", "spaced_seed_compat")
+    if not (os.path.exists(exe) and os.path.exists(exe2)):
+        pytest.skip("oracle/_ref/*_compat are built only where /root/reference exists")
+    gold = gold_json("locator_cli.json")
+    contig, texts = locator_cli_inputs()
+    cf = tmp_path / "contig.txt"
+    cf.write_bytes(contig + b"\n")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "pacbioassembly_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(cf), LOCATOR_CLI["pattern"]], input=b"\n".join(texts) + b"\n", capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rows = [[int(x) for x in line.split()] for line in r.stdout.decode().splitlines()]
+    assert [x[:4] for x in rows] == gold["rows"] and [x[4] for x in rows] == gold["col5"]
+    gold2 = gold_json("spaced_seed_cli.json")["runs"]
+    os.environ["LD_LIBRARY_PATH"] = env["LD_LIBRARY_PATH"]
+    got = run_spaced_seed_cli(exe2, str(tmp_path), [])
+    for name in gold2:
+        assert got[name] == gold2[name], (name, [k for k in gold2[name] if got[name][k] != gold2[name][k]])
 
 
 def test_spaced_seed_gpu_example_prints_what_the_reference_spaced_seed_prints(lib, tmp_path):

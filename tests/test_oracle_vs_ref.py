@@ -53,6 +53,39 @@ def test_align_random_full_scripts(oracle, ref):
             assert x["ops"].tolist() == y["ops"].tolist()
 
 
+def test_matrix_cells_get_cost_get_parent(oracle, ref):
+    """seq_aligner::get_cost / get_parent (seq_aligner.h:131-134, locator.cpp:86): every cell a call writes -- the
+    borders of init_cell, the band of every row swept, up to the row of an early failure -- holds the same cost and parent
+    in the oracle's matrix as in the reference's."""
+    rng = np.random.RandomState(12)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    for t in range(40):
+        la = int(rng.randint(12, 260))
+        a = alpha[rng.randint(0, 4, la)]
+        e = float(rng.choice([0.05, 0.2, 0.5]))
+        b = a[rng.rand(la) > e / 2].copy()
+        flip = rng.rand(b.size) < e / 2
+        b[flip] = alpha[rng.randint(0, 4, int(flip.sum()))]
+        b = np.concatenate([b, alpha[rng.randint(0, 4, int(rng.choice([0, 7, 90])))]])
+        if t % 3 == 0:
+            a, b = b, a
+        fwd = bool(t % 2)
+        x = oracle.align(a.tobytes(), b.tobytes(), 0.3, fwd, fwd)
+        y = ref.align(a.tobytes(), b.tobytes(), 0.3, fwd, fwd)
+        assert x["rc"] == y["rc"]
+        rows = x["fail_row"] if x["fail_row"] else x["len_a"]
+        md, n = x["max_dst"], 0
+        for i in range(0, rows + 1):
+            for j in range(max(0, i - md), min(x["len_b"], i + md) + 1):
+                if i == 0 and j > md:
+                    continue
+                assert oracle.cell(i, j) == ref.cell(i, j), (t, i, j)
+                n += 1
+        assert n > 100 and oracle.cell(rows + 1, rows + 1) is None
+        if x["rc"] >= 0 and x["len_b"] >= x["len_a"]:         # locator.cpp:86: the diagonal cell at the end of a
+            assert oracle.cell(x["len_a"], x["len_a"])[0] >= 0
+
+
 def test_stock_aligner_agrees_where_well_defined(oracle, ref):
     """The stock seq_aligner<26000,6000> typedef (no wide MAXM) agrees with the canonical one when 2*max_dst+1 <= MAXM."""
     g = eng.synth_genome(8, 40000)
