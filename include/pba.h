@@ -91,6 +91,9 @@ const char *pba_ctx_error(const pba_ctx *ctx);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own */
 int pba_ctx_set_stream(pba_ctx *ctx, void *hip_stream);
 int pba_ctx_sync(pba_ctx *ctx);
+/* The ctx keeps the work buffers of its drivers between calls (candidate arrays, per-read rows, traceback scratch: mapping
+ * gigabytes anew costs more than the kernels that use them).  pba_ctx_trim gives them back to the device. */
+int pba_ctx_trim(pba_ctx *ctx);
 /* HIP-event timings (on the ctx's stream) of the most recent pba_index_build / pba_locate /
  * pba_align_batch / pba_spaced_round on this ctx: measurement support for bench.py */
 typedef struct {

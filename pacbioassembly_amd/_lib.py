@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpba.so")
+LIB_PATH = os.environ.get("PBA_LIB_PATH") or os.path.join(HERE, "lib", "libpba.so")   # (PBA_LIB_PATH: a tuning build, tools/build_variant.py)
 
 PBA_OK = 0
 PBA_E_INVALID, PBA_E_NOMEM, PBA_E_HIP, PBA_E_TOOLONG, PBA_E_NODEVICE, PBA_E_ALPHABET = -1, -2, -3, -4, -5, -6
@@ -70,6 +70,7 @@ SYMBOLS = {
     "pba_ctx_error": (C.c_char_p, [_P]),
     "pba_ctx_set_stream": (C.c_int, [_P, _P]),
     "pba_ctx_sync": (C.c_int, [_P]),
+    "pba_ctx_trim": (C.c_int, [_P]),
     "pba_ctx_last_profile": (C.c_int, [_P, _P]),
     "pba_ctx_device_info": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_uint64)]),

@@ -21,10 +21,20 @@ struct AlignCfg {
 // Wavefronts per workgroup: the CU admits only 16 workgroups, so single-wave workgroups cap the bit-vector
 // kernel at 4 waves/SIMD; four independent waves per workgroup (one pair / read each, no barrier, own LDS
 // slice) lift that.  The row sweep keeps one wave per workgroup because its band row can take most of the LDS.
+// waves per SIMD the register allocator leaves room for (2nd __launch_bounds__ argument); tuning hooks -DPBA_BV_OCC12=n
+// (one or two blocks per lane) and -DPBA_BV_OCC34=n.  Measured on BASELINE configs[1] (NB = 2, profiles/r02_*): 5 -> 53.9 ms per
+// step, 6 -> 51.3, 7 -> 49.7, 8 -> 48.7: the step loop of two blocks fits 64 registers, and two more resident wavefronts
+// per SIMD fill the issue slots the ramp of every alignment leaves.
+#ifndef PBA_BV_OCC12
+#define PBA_BV_OCC12 8
+#endif
+#ifndef PBA_BV_OCC34
+#define PBA_BV_OCC34 6
+#endif
 template <int NB> struct Wpb {
     static constexpr int v = NB ? 4 : 1;
     // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
-    static constexpr int occ = NB == 0 ? 1 : (NB <= 4 ? 6 : 3);   // measured on configs[1]: 5 -> 123 ms, 6 -> 105 ms, 8 (spills in the step loop) -> 113 ms
+    static constexpr int occ = NB == 0 ? 1 : (NB <= 2 ? PBA_BV_OCC12 : (NB <= 4 ? PBA_BV_OCC34 : 3));
 };
 
 // need_diag: the caller reports D(m,m), the end of the diagonal (pba_result::diag_cost, locator.cpp:86)

@@ -410,6 +410,14 @@ k_ovl_items(const uint32_t *item_pre, const uint32_t *cand_off, uint32_t n_targe
     items[i] = make_uint2(lo, cand_off[lo] + (i - item_pre[lo]) * PBA_WAVE);
 }
 
+// waves per SIMD of the walk (tuning hooks, as in align_common.h).  Measured at 100 k reads (walk<2> then walk<3>): 6 / 6 ->
+// 288 ms, 8 / 6 -> 277 ms, 8 / 8 -> 270 ms.
+#ifndef PBA_OVL_OCC12
+#define PBA_OVL_OCC12 8
+#endif
+#ifndef PBA_OVL_OCC34
+#define PBA_OVL_OCC34 8
+#endif
 #define PBA_OVL_CHUNK 16          // work items a wavefront takes at a time (big inputs)
 #define PBA_OVL_S2_CAP 256        // survivors of the first prefilter stage a chunk can hand to the second
 
@@ -470,7 +478,7 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
 // Second launch (redo_in != nullptr, full_band): one parked (target, query) per work item, resumed at the parked
 // candidate with the reference band until the first success or the end of the query's candidates.
 template <int NB>
-static __global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 4 ? 6 : 3))
+static __global__ void __launch_bounds__(PBA_WAVE * (NB ? 4 : 1), NB == 0 ? 1 : (NB <= 2 ? PBA_OVL_OCC12 : (NB <= 4 ? PBA_OVL_OCC34 : 3)))
 k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint32_t *cand_cnt,
            const uint64_t *cand, OvlCfg cfg, int full_band, const uint2 *redo_in, uint2 *redo_out, unsigned long long redo_cap,
            unsigned long long *n_redo_out, pba_overlap *out, unsigned long long cap, unsigned long long *n_out,
@@ -484,7 +492,9 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
     // A million reads make hundreds of millions of light items (a group of 64 mostly false candidates): one atomic on
     // the queue and one on the pair counter per item is then what the walk waits for (every wavefront on the same two
     // addresses).  Items are taken up to 16 at a time and the pairs are added up per wavefront.
-    const uint32_t chunk = redo_in ? 1u : (n_items >= (1u << 17) ? (uint32_t)PBA_OVL_CHUNK : (n_items >= (1u << 14) ? 4u : 1u));
+    // (below a million items chunks cost more in load balance at the end of the launch than they save: an item with a true
+    // overlap is ~500 x a group of false candidates)
+    const uint32_t chunk = (redo_in || n_items < (1u << 20)) ? 1u : (uint32_t)PBA_OVL_CHUNK;
     // Two-stage prefilter over a chunk (first launch, bit-vector kernels): the first 32 rows of every candidate of the
     // chunk's groups (one candidate per lane, prefilter32), the survivors of ALL its groups listed in LDS and put
     // through rows 33..64 together (prefilter64, one survivor per lane) -- and only what passes both reaches the

@@ -99,6 +99,7 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     memset(&ctx->prof, 0, sizeof ctx->prof);
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+    memset(ctx->pool, 0, sizeof ctx->pool);
     // (kernels that take more than the default 64 KB of dynamic LDS are given the attribute by the translation unit
     // that launches them: tu_attrs() in each .hip)
     *out = ctx;
@@ -113,7 +114,17 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ctx->ev[i]);
     (void)hipFree(ctx->d_queue);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    for (auto &b : ctx->pool) if (b.p) (void)hipFree(b.p);
     delete ctx;
+}
+
+int pba_ctx_trim(pba_ctx *ctx) {
+    if (!ctx) return PBA_E_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto &b : ctx->pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (ctx->d_scratch) { (void)hipFree(ctx->d_scratch); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
+    return PBA_OK;
 }
 
 const char *pba_ctx_error(const pba_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }

@@ -25,25 +25,30 @@ __global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *ids, uint32_t n, int trials,
          int min_len, AlignCfg cfg, pba_loc_row *rows, LocAux *aux, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
+    __shared__ int4 s_grp[Wpb<NB>::v][PBA_WAVE];      // the hit group in flight: position, failed-cell prefix (lo, hi)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
     const PreThresholds pre_t(cfg.R);
     for (;;) {                                // persistent wavefront: pull the next read until the queue is dry
     const uint32_t slot = next_slot(queue);
     if (slot >= n) break;
-    const uint32_t r = ids ? ids[slot] : slot;
-    const int len = (int)Rd.len[r];
+    // (what a read's walk works with is the same in every lane; saying so keeps it in scalar registers instead of vector
+    // registers that the aligner's state then pushes out to scratch memory)
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ids ? ids[slot] : slot));
+    const int len = __builtin_amdgcn_readfirstlane((int)Rd.len[r]);
     int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, fdiag = -1, npairs = 0, nhit = 0, redo = 0;
     long long ncell = 0;
     if (len >= min_len) {                                                   // locator.cpp:72
         const PackedFetch rbase = fetch_of(Rd, r, 0, 1), tbase = fetch_of(T, tseq, 0, 1);
         const uint8_t *rseq = rbase.seq;
-        const int clen = (int)T.len[tseq];
+        const int clen = __builtin_amdgcn_readfirstlane((int)T.len[tseq]);
         for (int j = 0; j < trials && j < len && !found && !redo; ++j) {    // locator.cpp:74
-            const uint32_t key = window_key(rseq, (uint32_t)j, (uint32_t)len) & ix.mask;   // locator.cpp:75
+            const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)(window_key(rseq, (uint32_t)j, (uint32_t)len) & ix.mask));   // locator.cpp:75
             if (key == 0) continue;                                         // never inserted, locator.cpp:64
             uint32_t beg, cnt;
             ix_find(ix, key, beg, cnt);                                     // locator.cpp:76
+            beg = (uint32_t)__builtin_amdgcn_readfirstlane((int)beg);
+            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
             if (cnt == 0) continue;
             ++nhit;
             // locator.cpp:79, 64 hits at a time: every lane runs the first 32 rows of its hit (prefilter.h), then the
@@ -60,15 +65,39 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
                                        cfg.maxn, cfg.maxm, pre_t, po);
                     mycells = myfr ? band_cells(po.len_b, po.max_dst, myfr) : 0;
                 }
-                for (uint32_t hh = 0; hh < ng; ++hh) {
-                    const int fr = __builtin_amdgcn_readlane(myfr, (int)hh);
-                    if (fr) {                                               // failed at row fr <= 32: seq_aligner.h:185
-                        ++npairs;
-                        ncell += ((long long)__builtin_amdgcn_readlane((int)(mycells >> 32), (int)hh) << 32) |
-                                 (unsigned)__builtin_amdgcn_readlane((int)mycells, (int)hh);
-                        continue;
+                // The group's per-lane state goes to LDS before the array takes the wavefront (kept in registers it was
+                // spilled to scratch memory around every alignment): the hit position, and the running sum of the band
+                // cells of the hits that failed in their first 32 rows -- the hits between two survivors are counted
+                // from those sums, in list order, up to the first success.
+                const uint64_t fmask = __builtin_amdgcn_ballot_w64(myfr != 0);
+                uint64_t surv = __builtin_amdgcn_ballot_w64(act && myfr == 0);
+                long long pc = mycells;                                 // inclusive prefix over the lanes
+#pragma unroll
+                for (int d = 1; d < PBA_WAVE; d <<= 1) {
+                    const long long up = ((long long)__shfl_up((int)(pc >> 32), d, PBA_WAVE) << 32) | (unsigned)__shfl_up((int)pc, d, PBA_WAVE);
+                    if ((int)lane >= d) pc += up;
+                }
+                __builtin_amdgcn_wave_barrier();                        // (the previous group's reads are done)
+                s_grp[wave][lane] = make_int4(mypos, (int)pc, (int)(pc >> 32), 0);
+                __builtin_amdgcn_wave_barrier();
+                auto cells_upto = [&](uint32_t n_lanes) -> long long {  // failed cells of lanes [0, n_lanes)
+                    if (n_lanes == 0) return 0ll;
+                    const int4 g = s_grp[wave][n_lanes - 1];
+                    return ((long long)__builtin_amdgcn_readfirstlane(g.z) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(g.y);
+                };
+                uint32_t from = 0;
+                auto count_failed = [&](uint32_t to) {                  // hits [from, to) that failed: seq_aligner.h:185
+                    if (to > from) {
+                        const uint64_t m = fmask & (to >= PBA_WAVE ? ~0ull : (1ull << to) - 1ull) & ~((1ull << from) - 1ull);
+                        if (m) { npairs += __builtin_popcountll(m); ncell += cells_upto(to) - cells_upto(from); }
                     }
-                    const int pos = __builtin_amdgcn_readlane(mypos, (int)hh);
+                };
+                while (surv) {
+                    const uint32_t hh = (uint32_t)__builtin_ctzll(surv);
+                    surv &= surv - 1ull;
+                    count_failed(hh);
+                    from = hh + 1;
+                    const int pos = __builtin_amdgcn_readfirstlane(s_grp[wave][hh].x);
                     const PackedFetch fa = rbase.at(j, 1);                  // a = read from j   (locator.cpp:78)
                     const PackedFetch fb = tbase.at(pos, 1);                // b = contig from pos (locator.cpp:80)
                     AlnOut o;
@@ -81,6 +110,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
                         break;
                     }
                 }
+                if (!found && !redo) count_failed(ng);
             }
         }
     }
@@ -223,9 +253,9 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     Plan pl;
     int st = make_plan(ctx, R, maxn, maxm, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (st != PBA_OK) return st;
-    DevBuf d_rows, d_aux, d_ids;
-    HIPCHK(hipMalloc(&d_rows.p, sizeof(pba_loc_row) * (n + 1)));
-    HIPCHK(hipMalloc(&d_aux.p, sizeof(LocAux) * (n + 1)));
+    BufRef d_rows, d_aux, d_ids;                               // (pooled in the ctx: two hipMalloc / hipFree pairs were 1 ms of a 50 ms step)
+    POOL(POOL_LOC_ROWS, sizeof(pba_loc_row) * ((size_t)n + 1), d_rows.p);
+    POOL(POOL_LOC_AUX, sizeof(LocAux) * ((size_t)n + 1), d_aux.p);
     std::vector<LocAux> aux(n + 1);
 #define K_LOC(NBV)                                                                                                   \
     (void)hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream);                                                           \
@@ -248,7 +278,7 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
         for (uint32_t r = 0; r < n; ++r)
             if (aux[r].redo) redo.push_back(r);
         if (!redo.empty()) {      // reads with an uncertified pair: walk them again at the reference band
-            HIPCHK(hipMalloc(&d_ids.p, sizeof(uint32_t) * redo.size()));
+            POOL(POOL_LOC_IDS, sizeof(uint32_t) * redo.size(), d_ids.p);
             HIPCHK(hipMemcpyAsync(d_ids.p, redo.data(), sizeof(uint32_t) * redo.size(), hipMemcpyHostToDevice, ctx->stream));
             pl.cfg.full_band = 1;
             const uint32_t cnt = (uint32_t)redo.size();

@@ -24,7 +24,13 @@
 #define PBA_INTERNAL __attribute__((visibility("hidden")))
 // a kernel that takes more than the default 64 KB of dynamic LDS; every translation unit does this once for the kernels
 // it launches (tu_attrs() in each .hip; one process drives one GPU)
-#define PBA_BIG_LDS(kernel) (void)hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+// (128 KB of dynamic LDS: the largest LDS sort and the largest band row, with room for a kernel's static arrays; a refused
+// attribute must not linger as the thread's last error)
+#define PBA_BIG_LDS(kernel)                                                                                            \
+    do {                                                                                                               \
+        if (hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) \
+            (void)hipGetLastError();                                                                                   \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // host-side objects
@@ -37,6 +43,10 @@ struct pba_ctx {
     uint32_t *d_queue;       // work-queue counters of the persistent aligning kernels (one per launch in flight)
     void *d_scratch;         // parent-bit scratch of the trace / vote kernels, kept between calls (tens of GB: mapping
     size_t scratch_bytes;    // it anew on every call cost seconds); grown on demand, freed with the ctx
+    // Work buffers of the drivers, kept between calls for the same reason (hipMalloc / hipFree of the 11 GB candidate
+    // array of a million-read target range cost more than the kernels that fill it; the 4 MB of per-read rows of a
+    // locate step cost 1 ms of a 50 ms step): grown on demand (pool_reserve), released by pba_ctx_trim or with the ctx.
+    struct { void *p; size_t cap; } pool[16];
     pba_profile prof;
     char err[512];
 };
@@ -87,6 +97,40 @@ static const int kMaxSeqLen = 65000;            // u16 DP costs: D(i,j) <= max(i
 static const int kRowSweepLdsCap = 96 * 1024;   // LDS bytes one wavefront may take for its band row
 static const size_t kSlack = 1024;              // readable bytes before the first and after the last packed byte
                                                 // (the bit-vector kernel streams a few hundred bases past an accessor)
+
+// pool slots
+enum { POOL_OVL_CAND = 0, POOL_OVL_TMP, POOL_OVL_ITEMS, POOL_OVL_REDO, POOL_OVL_REDO_IN, POOL_OVL_OUT, POOL_OVL_SMALL,
+       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_CNT };
+// a buffer of at least `bytes` in pool slot `slot` (contents undefined); grows by reallocation with 1/8 headroom
+static inline int pool_reserve(pba_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (ctx->pool[slot].cap < bytes) {
+        if (ctx->pool[slot].p) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(ctx->pool[slot].p);
+            ctx->pool[slot].p = nullptr; ctx->pool[slot].cap = 0;
+        }
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&ctx->pool[slot].p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&ctx->pool[slot].p, bytes); if (e == hipSuccess) ctx->pool[slot].cap = bytes; }
+        else ctx->pool[slot].cap = want;
+        if (e != hipSuccess) { ctx->pool[slot].p = nullptr; return ctx_fail(ctx, PBA_E_NOMEM, "work buffer", e); }
+    }
+    *out = ctx->pool[slot].p;
+    return PBA_OK;
+}
+#define POOL(slot, bytes, ptr)                                                     \
+    do {                                                                           \
+        void *p__ = nullptr;                                                       \
+        int st__ = pool_reserve(ctx, (slot), (bytes), &p__);                       \
+        if (st__ != PBA_OK) return st__;                                           \
+        (ptr) = (decltype(ptr))p__;                                                \
+    } while (0)
+
+// a pooled buffer seen through the same face as a DevBuf (not owned: the ctx keeps it)
+struct BufRef {
+    void *p = nullptr;
+    template <class T> T *as() const { return (T *)p; }
+};
 
 // RAII for temporaries so early returns do not leak device memory
 struct DevBuf {

@@ -196,10 +196,11 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     HIPCHK(hipMalloc(&d_cnt64.p, 32));
 
     // 1. count: the slice of the candidate array every target needs
-    DevBuf d_slice, d_off, d_valid, d_cand, d_tmp, d_out;
-    HIPCHK(hipMalloc(&d_slice.p, sizeof(uint32_t) * (nt + 1)));
-    HIPCHK(hipMalloc(&d_off.p, sizeof(uint32_t) * (nt + 1)));
-    HIPCHK(hipMalloc(&d_valid.p, sizeof(uint32_t) * (nt + 1)));
+    BufRef d_slice, d_off, d_valid, d_cand, d_tmp, d_out, d_small;
+    // (the big arrays of a call live in the ctx's pool: at a million reads a target range needs 11 GB of candidates twice,
+    // and mapping those anew for each of the 40 ranges took longer than everything the kernels do)
+    POOL(POOL_OVL_SMALL, sizeof(uint32_t) * 4 * ((size_t)nt + 1), d_small.p);
+    d_slice.p = d_small.as<uint32_t>(); d_off.p = d_small.as<uint32_t>() + (nt + 1); d_valid.p = d_small.as<uint32_t>() + 2 * ((size_t)nt + 1);
     (void)hipEventRecord(ctx->ev[2], ctx->stream);
     if (tab->hashed) hipLaunchKernelGGL(k_ovl_count<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
     else hipLaunchKernelGGL(k_ovl_count<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
@@ -207,19 +208,20 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-    uint64_t total = 0;
+    uint64_t total = 0, max_cand = PBA_OVL_MAX_CANDIDATES;
+    if (const char *e = getenv("PBA_OVL_MAX_CANDIDATES")) max_cand = std::min<uint64_t>(max_cand, (uint64_t)atoll(e));   // test hook: the limit at test sizes
     uint32_t biggest_small = 2;
     std::vector<uint32_t> big;                                   // targets whose slice outgrows one LDS sort
     for (uint32_t i = 0; i < nt; ++i) {
         h_off[i] = (uint32_t)total;
         total += h_slice[i];
-        if (total >= PBA_OVL_MAX_CANDIDATES) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
+        if (total >= max_cand) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
         if (h_slice[i] <= PBA_IX_LDS_SORT_CAP) biggest_small = std::max(biggest_small, h_slice[i]);
         else big.push_back(i);
     }
     h_off[nt] = (uint32_t)total;
     HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMalloc(&d_cand.p, sizeof(uint64_t) * (total + 1)));
+    POOL(POOL_OVL_CAND, sizeof(uint64_t) * (total + 1), d_cand.p);
 
     // 2. fill: the candidates (all-ones where a slot belongs to the target's own probe or to another key)
     if (total) {
@@ -243,7 +245,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
             st.n_big_targets = (uint32_t)big.size();
             DevBuf d_big, d_pieces, d_pc;
             const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // fine bucket = umulhi(q, sub_mul)
-            HIPCHK(hipMalloc(&d_tmp.p, sizeof(uint64_t) * (total + 1)));
+            POOL(POOL_OVL_TMP, sizeof(uint64_t) * (total + 1), d_tmp.p);
             HIPCHK(hipMalloc(&d_big.p, sizeof(uint32_t) * big.size()));
             HIPCHK(hipMalloc(&d_pieces.p, sizeof(OvlPiece) * big.size() * PBA_OVL_SUB));
             HIPCHK(hipMalloc(&d_pc.p, 8));
@@ -276,23 +278,22 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-    d_tmp.reset();                                               // (the second buffer goes before the walk allocates)
     uint64_t n_valid = 0;
     for (uint32_t i = 0; i < nt; ++i) n_valid += h_valid[i];
     st.n_candidates = n_valid;
 
     // 4. walk: persistent wavefronts, one target at a time, narrow window; then the parked (target, query) runs
     //    at the reference band
-    HIPCHK(hipMalloc(&d_out.p, sizeof(pba_overlap) * (cap + 1)));
+    POOL(POOL_OVL_OUT, sizeof(pba_overlap) * (cap + 1), d_out.p);
     HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 32, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
     OvlCfg ocfg;
     ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
     const size_t lds = pl.lds;
-    DevBuf d_redo, d_items;
+    BufRef d_redo, d_items;
     // every (target, query) run can park at most once per stage, and there are no more runs than candidates
     const uint64_t redo_cap = std::max<uint64_t>(1024, n_valid);
-    HIPCHK(hipMalloc(&d_redo.p, sizeof(uint2) * redo_cap));
+    POOL(POOL_OVL_REDO, sizeof(uint2) * redo_cap, d_redo.p);
     // work items: (target, first candidate of a group of 64), expanded on the device from the per-target item counts
     // (a million reads make 22 M items per call: building and copying them from the host took longer than a scan pass)
     std::vector<uint32_t> h_ipre(nt + 1);
@@ -300,10 +301,10 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     for (uint32_t i = 0; i < nt; ++i) { h_ipre[i] = (uint32_t)n_items64; n_items64 += (h_valid[i] + PBA_WAVE - 1) / PBA_WAVE; }
     if (n_items64 >= 0xFFFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: too many work items per call, use a smaller target range");
     h_ipre[nt] = (uint32_t)n_items64;
-    DevBuf d_ipre;
-    HIPCHK(hipMalloc(&d_ipre.p, sizeof(uint32_t) * (nt + 1)));
+    BufRef d_ipre;
+    d_ipre.p = d_small.as<uint32_t>() + 3 * ((size_t)nt + 1);
     HIPCHK(hipMemcpyAsync(d_ipre.p, h_ipre.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMalloc(&d_items.p, sizeof(uint2) * (n_items64 + 1)));
+    POOL(POOL_OVL_ITEMS, sizeof(uint2) * (n_items64 + 1), d_items.p);
     if (n_items64)
         hipLaunchKernelGGL(k_ovl_items, dim3((uint32_t)((n_items64 + 255) / 256)), dim3(256), 0, ctx->stream, d_ipre.as<uint32_t>(),
                            d_off.as<uint32_t>(), nt, (uint32_t)n_items64, d_items.as<uint2>());
@@ -337,8 +338,8 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
             if (stage == 0) *parked = h_redo;
             if (!h_redo) return PBA_OK;
             if (stage == 0 && nb_mid <= nb_first) continue;      // no ring between this one and the reference band's
-            DevBuf d_in;
-            HIPCHK(hipMalloc(&d_in.p, sizeof(uint2) * h_redo));
+            BufRef d_in;
+            POOL(POOL_OVL_REDO_IN, sizeof(uint2) * h_redo, d_in.p);
             HIPCHK(hipMemcpyAsync(d_in.p, d_redo.p, sizeof(uint2) * h_redo, hipMemcpyDeviceToDevice, ctx->stream));
             rc2 = stage == 0 ? walk(nb_mid, nullptr, (uint32_t)h_redo, 0, d_in.as<uint2>())
                              : walk(pl.nb2, nullptr, (uint32_t)h_redo, 1, d_in.as<uint2>());

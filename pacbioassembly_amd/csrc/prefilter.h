@@ -18,13 +18,24 @@
 #define PBA_PRE_ROWS 32
 
 // floor(i * R) for i = 0..32, FP64 exactly as the reference forms i*R; an integer d satisfies
-// (double)d > (double)i*R  <=>  d > floor((double)i*R)
+// (double)d > (double)i*R  <=>  d > floor((double)i*R).  R < 1, so a threshold fits a byte: four to a register (33 separate
+// scalars were more than the scalar file had left next to the aligner's state -- they ended up in scratch memory, one
+// scratch load per column of the sweep).
 struct PreThresholds {
-    int t[PBA_PRE_ROWS + 1];
+    uint32_t p[(PBA_PRE_ROWS + 4) / 4];
     __device__ __forceinline__ explicit PreThresholds(double R) {
 #pragma unroll
-        for (int i = 0; i <= PBA_PRE_ROWS; ++i) t[i] = __builtin_amdgcn_readfirstlane((int)floor((double)i * R));
+        for (int w = 0; w < (PBA_PRE_ROWS + 4) / 4; ++w) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = 4 * w + b;
+                if (i <= PBA_PRE_ROWS) x |= (uint32_t)(int)floor((double)i * R) << (8 * b);
+            }
+            p[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+        }
     }
+    __device__ __forceinline__ int at(int i) const { return (int)((p[i >> 2] >> (8 * (i & 3))) & 0xFFu); }
 };
 
 // the sweep itself: a's first 32 elements as rows (alo / ahi), b's first 32 as columns (blo / bhi: bit k = column k+1)
@@ -45,7 +56,7 @@ __device__ __forceinline__ int prefilter32_planes(uint32_t alo, uint32_t ahi, ui
         Mh <<= 1;
         Pv = Mh | ~(Xv | Ph);
         Mv = Ph & Xv;
-        if (k + 1 > 10 && fr == 0 && score > T.t[k + 1]) fr = k + 1;
+        if (k + 1 > 10 && fr == 0 && score > T.at(k + 1)) fr = k + 1;
     }
     return fr;
 }

@@ -159,6 +159,10 @@ class Context:
     def sync(self):
         self.check(self.lib.pba_ctx_sync(self.h), "sync")
 
+    def trim(self):
+        """Give the work buffers kept between calls back to the device (pba_ctx_trim)."""
+        self.check(self.lib.pba_ctx_trim(self.h), "trim")
+
     def last_profile(self) -> dict:
         pr = _lib.PbaProfile()
         self.check(self.lib.pba_ctx_last_profile(self.h, C.byref(pr)), "last_profile")

@@ -721,6 +721,68 @@ def test_read_shards_exported_and_regathered_give_the_same_overlaps(ctx):
     assert e.value.status == -1
 
 
+def test_overlap_many_target_ranges_and_the_limits_of_a_call(ctx, oracle, monkeypatch):
+    """BASELINE config 5's way through the engine at a size a test can afford: 200 000 short reads, ONE probe table, the
+    targets in 25 ranges -- same overlaps and the same number of pairs as one call over everything, the oracle's
+    composition on sampled targets of different ranges -- and the limits of a call answer PBA_E_TOOLONG instead of a
+    wrapped count: candidates per call (here lowered through the test hook), probe ids beyond 32 bits."""
+    import torch
+    from pacbioassembly_amd import ProbeTable
+    n, rl = 200_000, 500
+    g = eng.synth_genome(401, n * rl // 20)
+    reads, offs, _ = eng.synth_reads(402, g, n, rl, nthreads=16)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    S = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    one, st1 = ctx.overlap_all(S, mask, 0.30, 32, 64, cap=n * 80)
+    assert st1["n_overlaps"] == len(one) > 500_000 and st1["n_candidates"] > 50_000_000
+    many, stm = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=8000, cap_per_target=400)
+    assert (many == one).all() and stm["n_pairs"] == st1["n_pairs"] and stm["n_candidates"] == st1["n_candidates"]
+    texts = lambda i: reads[int(offs[i]):int(offs[i + 1])].tobytes()
+    file = b"".join(eng.text2bin(texts(i)) for i in range(n))
+    rec_offs = (np.arange(n, dtype=np.uint64) * np.uint64(4 + (rl + 3) // 4))
+    for t in (0, 7999, 8000, 123_456, n - 1):
+        rows = oracle.spaced_round(texts(t), mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=16)
+        exp = [(t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]), int(rows["matlen_a"][q]),
+                int(rows["matlen_b"][q])) for q in np.nonzero(rows["found"])[0] if q != t]
+        lo, hi = np.searchsorted(many["target"], [t, t + 1])
+        assert [tuple(int(x) for x in r) for r in many[lo:hi]] == exp and len(exp) >= 1, t
+    # a call that would hold more candidates than its offsets can address refuses; ranges below the limit go through
+    monkeypatch.setenv("PBA_OVL_MAX_CANDIDATES", str(st1["n_candidates"] // 10))
+    with pytest.raises(PbaError) as e:
+        ctx.overlap_all(S, mask, 0.30, 32, 64, cap=16)
+    assert e.value.status == -4                                      # PBA_E_TOOLONG
+    again, sta = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=8000, cap_per_target=400)
+    assert sta["n_overlaps"] == st1["n_overlaps"]
+    monkeypatch.delenv("PBA_OVL_MAX_CANDIDATES")
+    # probe ids are 32 bits: reads x 2 x max_trial must stay below 2^32 (refused before anything is read)
+    buf = torch.zeros(16, dtype=torch.int64, device="cuda")
+    with pytest.raises(PbaError) as e:
+        ProbeTable(ctx, buf.data_ptr(), 1 << 32, mask, 32)
+    assert e.value.status == -4
+    with pytest.raises(PbaError) as e:                               # max_trial beyond what a candidate's 7 probe bits hold
+        ProbeTable(ctx, buf.data_ptr(), 16, mask, 64)
+    assert e.value.status == -1
+
+
+def test_locate_baseline_config1_shape_256_reads_vs_oracle(ctx, oracle):
+    """BASELINE configs[1] at its own shape (15 kb reads @15 % against the 5 Mb genome, R = 0.30, 50 probe offsets), 256
+    reads of it: every row, the pair count and the band-cell count of every read against the oracle on the host cores."""
+    g = eng.synth_genome(2, 5_000_000)
+    reads, offs, _ = eng.synth_reads(3, g, 256, 15_000, 0.05, 0.05, 0.05, nthreads=16)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    T = ctx.seqs_from_text(g, np.array([0, g.size], np.uint64), strict_acgt=True)
+    Rd = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    ix = ctx.index_build(T, 0, mask, PBA_INDEX_ALL)
+    oracle.prefault(16, 15_000, 0.30)
+    want, wst = oracle.locator(g, mask, 0.30, reads, offs, 50, 500, nthreads=16)
+    oracle.release()
+    rows, st = ctx.locate(ix, T, 0, Rd, 0.30, 50, 500)
+    for c in ("nseq", "found", "j", "pos", "cost", "seglen", "matlen_a", "matlen_b", "n_pairs"):
+        assert (rows[c] == want[c]).all(), c
+    assert st == wst and wst["n_located"] > 180 and wst["n_pairs"] > 1500 and wst["n_cells"] > 2 * 10 ** 10
+    assert (rows["diag_cost"][rows["found"] == 1] >= rows["cost"][rows["found"] == 1]).all()
+
+
 def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):
     """6.5 kb reads at ~12 % error each overlap at ~24 % between them: the first-pass window (1 384 in a one-block ring)
     cannot certify the longest true overlaps, the (target, query) run is parked and resumed at the reference band by
