@@ -67,13 +67,18 @@ struct HeadTail {
 //   bucket(key) = the key's care bits gathered into one number when the mask has <= PBA_PT_MAX_BITS of them (every key
 //                 its own bucket: a lookup is ONE load of two adjacent offsets, no search, no key compare), else a
 //                 multiplicative hash into 2^PBA_PT_MAX_BITS buckets (HASHED: the entry's key is kept and compared)
-//   start[b] .. start[b+1] : the bucket's entries in pid[] (and pkey[] when HASHED)
+//   rec[b]   = { first entry of bucket b in pid[] (and pkey[] when HASHED), pid of that first entry }: one 16-byte load of
+//              rec[b], rec[b+1] gives the bucket's extent AND its first entry -- five buckets in six hold a single entry
+//              up to ~100 k reads, so the lookup of a position costs ONE line from beyond L2, which is what the scan is
+//              bound by (PMC: both passes sit at ~53 G random 64-byte lines per second from the Infinity Cache)
+//   start[]  = the same offsets as a plain u32 array (the table is built on it; 4 B per bucket instead of 8 for the count pass)
 //   pid[i]   = query << 7 | (2j + backward)
 //   presence = one bit per bucket (2 MB for the weight-12 masks of seeds.txt: resident in every XCD's L2), consulted
 //              first -- with 20 k reads 12 of 13 positions stop there, with a million reads none do
 #define PBA_PT_MAX_BITS 26
 struct ProbeTab {
     uint32_t *start, *pid, *pkey, *presence;
+    uint2 *rec;
     uint32_t mask, mv[5];
     int bits;
 };
@@ -113,6 +118,15 @@ k_pt_fill(const uint64_t *in, uint64_t n, ProbeTab T, uint32_t *cursor, uint32_t
     const uint32_t slot = atomicAdd(cursor + pt_bucket<HASHED>(T, key), 1u);
     T.pid[slot] = (gid / t2) << PBA_OVL_JD_BITS | (gid % t2);
     if (HASHED) T.pkey[slot] = key;
+}
+
+// rec[b] = { start[b], pid[start[b]] } once the entries are in place
+static __global__ void __launch_bounds__(256)
+k_pt_pack(ProbeTab T, uint64_t n_buckets_plus_1, uint32_t n_entries) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets_plus_1) return;
+    const uint32_t s = T.start[b];
+    T.rec[b] = make_uint2(s, s < n_entries ? T.pid[s] : 0u);
 }
 
 // In-place inclusive scan of a[0 .. n) in three launches: tiles of PBA_SCAN_TILE per workgroup, the tile sums by one
@@ -182,7 +196,10 @@ k_scan_add(uint32_t *a, uint64_t n, const uint32_t *tile_pre) {
 // (0.08 per position at 20 k reads, 3.8 at a million).
 #define PBA_OVL_PPT 16                                         // positions per thread and step
 #define PBA_OVL_WAVES 4                                        // wavefronts per workgroup
-#define PBA_OVL_RUNS (PBA_WAVE * PBA_OVL_PPT)                  // runs a wavefront can meet in one step
+#ifndef PBA_OVL_HALF
+#define PBA_OVL_HALF 16                                        // positions per thread whose runs are compacted together
+#endif
+#define PBA_OVL_RUNS (PBA_WAVE * PBA_OVL_HALF)                 // runs a wavefront can meet in one round
 
 struct TargetWalk {          // visiting order of ref_seq::get_seedmap as a function of the position
     int nhead, tail_lo, tail_top, nchunks;
@@ -219,9 +236,9 @@ k_ovl_count(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_
 #pragma unroll
         for (int k = 0; k < PBA_OVL_PPT; ++k) {
             const bool hit = b[k] != 0xFFFFFFFFu && ((pw[k] >> (b[k] & 31)) & 1u);
-            const uint32_t *sp = T.start + (hit ? b[k] : 0u);
-            const uint32_t s0 = sp[0], s1 = sp[1];
-            sum += hit ? s1 - s0 : 0u;
+            uint2 se;                                                   // the bucket's offset pair in one 8-byte load
+            __builtin_memcpy(&se, T.start + (hit ? b[k] : 0u), 8);
+            sum += hit ? se.y - se.x : 0u;
         }
     }
 #pragma unroll
@@ -241,6 +258,7 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
     __shared__ uint32_t r_s0[PBA_OVL_WAVES][PBA_OVL_RUNS];         // first entry of the run
     __shared__ uint32_t r_rel[PBA_OVL_WAVES][PBA_OVL_RUNS + 1];    // its first slot, relative to the step's reservation
     __shared__ uint16_t r_ord[PBA_OVL_WAVES][PBA_OVL_RUNS];        // ordinal of the position
+    __shared__ uint32_t r_first[PBA_OVL_WAVES][PBA_OVL_RUNS];      // its first entry (came with the bucket's record)
     __shared__ uint32_t r_key[HASHED ? PBA_OVL_WAVES : 1][HASHED ? PBA_OVL_RUNS : 1];
     __shared__ uint32_t cursor, nvalid;
     const uint32_t tl = blockIdx.x, t = t_lo + tl;
@@ -267,17 +285,23 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
             b[k] = ok ? pt_bucket<HASHED>(T, key[k]) : 0xFFFFFFFFu;
             pw[k] = T.presence[ok ? b[k] >> 5 : 0u];
         }
-        uint32_t s0[PBA_OVL_PPT], n[PBA_OVL_PPT], tot = 0, nruns = 0;
+        uint32_t s0[PBA_OVL_PPT], n[PBA_OVL_PPT], first[PBA_OVL_PPT];
 #pragma unroll
         for (int k = 0; k < PBA_OVL_PPT; ++k) {
             const bool hit = b[k] != 0xFFFFFFFFu && ((pw[k] >> (b[k] & 31)) & 1u);
-            const uint32_t *sp = T.start + (hit ? b[k] : 0u);
-            const uint32_t a0 = sp[0], a1 = sp[1];
-            s0[k] = a0; n[k] = hit ? a1 - a0 : 0u;
-            tot += n[k]; nruns += n[k] != 0u;
+            uint4 se;                                                   // rec[b], rec[b + 1] in one 16-byte load
+            __builtin_memcpy(&se, T.rec + (hit ? b[k] : 0u), 16);
+            s0[k] = se.x; n[k] = hit ? se.z - se.x : 0u; first[k] = se.y;
         }
+        // the runs of the step are compacted and emitted in PBA_OVL_PPT / PBA_OVL_HALF rounds (tuning hook; measured at 100 k
+        // reads: one round of 16 -> 34.7 ms for the scan, two of 8 (half the LDS, twice the workgroups per CU) -> 36.4)
+#pragma unroll
+        for (int h0 = 0; h0 < PBA_OVL_PPT; h0 += PBA_OVL_HALF) {
+        uint32_t tot_h = 0, nruns_h = 0;
+#pragma unroll
+        for (int k = h0; k < h0 + PBA_OVL_HALF; ++k) { tot_h += n[k]; nruns_h += n[k] != 0u; }
         // exclusive prefix over the lanes: where this lane's runs go in the run list, and its entries in the reservation
-        uint32_t run_at = nruns, slot_at = tot;
+        uint32_t run_at = nruns_h, slot_at = tot_h;
 #pragma unroll
         for (int d = 1; d < PBA_WAVE; d <<= 1) {
             const uint32_t a = __shfl_up(run_at, d, PBA_WAVE), s = __shfl_up(slot_at, d, PBA_WAVE);
@@ -286,11 +310,12 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
         const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)run_at, PBA_WAVE - 1);
         const uint32_t Tot = (uint32_t)__builtin_amdgcn_readlane((int)slot_at, PBA_WAVE - 1);
         if (R == 0) continue;                                        // (wave-uniform)
-        run_at -= nruns; slot_at -= tot;
+        run_at -= nruns_h; slot_at -= tot_h;
 #pragma unroll
-        for (int k = 0; k < PBA_OVL_PPT; ++k) {
+        for (int k = h0; k < h0 + PBA_OVL_HALF; ++k) {
             if (n[k]) {
                 r_s0[w][run_at] = s0[k]; r_rel[w][run_at] = slot_at; r_ord[w][run_at] = (uint16_t)tw.ord_of(16 * c + k);
+                r_first[w][run_at] = first[k];
                 if (HASHED) r_key[w][run_at] = key[k];
                 ++run_at; slot_at += n[k];
             }
@@ -306,7 +331,7 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
             const uint32_t want = HASHED ? r_key[w][r] : 0u;
             uint64_t *o = out + base + rel;
             for (uint32_t h = 0; h < cnt; ++h) {
-                const uint32_t pe = T.pid[e0 + h];
+                const uint32_t pe = h ? T.pid[e0 + h] : r_first[w][r];
                 const uint32_t q = pe >> PBA_OVL_JD_BITS;
                 bool ok = q != t;
                 if (HASHED) ok = ok && T.pkey[e0 + h] == want;
@@ -315,7 +340,8 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
                 myvalid += ok;
             }
         }
-        __builtin_amdgcn_wave_barrier();                             // before the next step overwrites the list
+        __builtin_amdgcn_wave_barrier();                             // before the next round overwrites the list
+        }
     }
 #pragma unroll
     for (int d = 1; d < PBA_WAVE; d <<= 1) myvalid += __shfl_xor(myvalid, d, PBA_WAVE);

@@ -100,6 +100,7 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
     memset(ctx->pool, 0, sizeof ctx->pool);
+    memset(&ctx->ix_cache, 0, sizeof ctx->ix_cache);
     // (kernels that take more than the default 64 KB of dynamic LDS are given the attribute by the translation unit
     // that launches them: tu_attrs() in each .hip)
     *out = ctx;
@@ -115,6 +116,8 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     (void)hipFree(ctx->d_queue);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (auto &b : ctx->pool) if (b.p) (void)hipFree(b.p);
+    if (ctx->ix_cache.ent) (void)hipFree(ctx->ix_cache.ent);
+    if (ctx->ix_cache.off) (void)hipFree(ctx->ix_cache.off);
     delete ctx;
 }
 
@@ -123,6 +126,9 @@ int pba_ctx_trim(pba_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto &b : ctx->pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (ctx->ix_cache.ent) (void)hipFree(ctx->ix_cache.ent);
+    if (ctx->ix_cache.off) (void)hipFree(ctx->ix_cache.off);
+    memset(&ctx->ix_cache, 0, sizeof ctx->ix_cache);
     if (ctx->d_scratch) { (void)hipFree(ctx->d_scratch); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
     return PBA_OK;
 }
@@ -394,10 +400,23 @@ int pba_seqs_get_text(pba_ctx *ctx, const pba_seqs *s, uint32_t i, char *text, s
 // ---------------------------------------------------------------------------------------------
 void pba_index_destroy(pba_index *ix) {
     if (!ix) return;
-    (void)hipSetDevice(ix->ctx->device);
-    if (ix->d_ent) (void)hipFree(ix->d_ent);
-    if (ix->d_part_off) (void)hipFree(ix->d_part_off);
+    pba_ctx *ctx = ix->ctx;
+    (void)hipSetDevice(ctx->device);
+    // the arrays go to the ctx's one-deep cache when it is empty (the work that used them was synchronised by the call
+    // that returned its results), else back to the device
+    if (ix->d_ent && !ctx->ix_cache.ent) { ctx->ix_cache.ent = ix->d_ent; ctx->ix_cache.ent_cap = ix->ent_cap; }
+    else if (ix->d_ent) (void)hipFree(ix->d_ent);
+    if (ix->d_part_off && !ctx->ix_cache.off) { ctx->ix_cache.off = ix->d_part_off; ctx->ix_cache.off_cap = ix->off_cap; }
+    else if (ix->d_part_off) (void)hipFree(ix->d_part_off);
     delete ix;
+}
+
+// device array of at least `bytes` for a new index: the cached one if it is large enough
+static int ix_alloc(pba_ctx *ctx, void **cache, size_t *cache_cap, size_t bytes, void **out, size_t *cap) {
+    if (*cache && *cache_cap >= bytes) { *out = *cache; *cap = *cache_cap; *cache = nullptr; *cache_cap = 0; return PBA_OK; }
+    HIPCHK(hipMalloc(out, bytes));
+    *cap = bytes;
+    return PBA_OK;
 }
 
 uint64_t pba_index_entries(const pba_index *ix) { return ix ? ix->n_entries : 0; }
@@ -465,13 +484,14 @@ static pba_index *index_new(pba_ctx *ctx, uint32_t mask, uint32_t len, int mode,
     if (!ix) return nullptr;
     ix->ctx = ctx; ix->mask = mask; ix->seq_len = len; ix->visited = v.visited; ix->nhead = v.nhead;
     ix->tail_top = v.tail_top; ix->mode = mode; ix->n_entries = 0; ix->d_ent = nullptr; ix->d_part_off = nullptr;
+    ix->ent_cap = ix->off_cap = 0;
     ix->logP = 0;
     return ix;
 }
 
 // counts are in cnt (device, P+1 u32): turn them into offsets, allocate the entry array, let `scatter`
 // fill it (cnt then holds the cursors), sort every partition
-static int index_finish(pba_ctx *ctx, pba_index *ix, DevBuf &cnt, const std::function<void()> &scatter) {
+static int index_finish(pba_ctx *ctx, pba_index *ix, BufRef &cnt, const std::function<void()> &scatter) {
     const uint32_t P = 1u << ix->logP;
     std::vector<uint32_t> h_cnt(P + 1, 0), h_off(P + 1, 0);
     HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, ctx->stream));
@@ -482,8 +502,9 @@ static int index_finish(pba_ctx *ctx, pba_index *ix, DevBuf &cnt, const std::fun
     if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "more than 2^32 index entries");
     h_off[P] = (uint32_t)total;
     ix->n_entries = total;
-    HIPCHK(hipMalloc((void **)&ix->d_ent, sizeof(uint64_t) * (total + 1)));
-    HIPCHK(hipMalloc((void **)&ix->d_part_off, sizeof(uint32_t) * (P + 1)));
+    int sta = ix_alloc(ctx, &ctx->ix_cache.ent, &ctx->ix_cache.ent_cap, sizeof(uint64_t) * (total + 1), (void **)&ix->d_ent, &ix->ent_cap);
+    if (sta == PBA_OK) sta = ix_alloc(ctx, &ctx->ix_cache.off, &ctx->ix_cache.off_cap, sizeof(uint32_t) * (P + 1), (void **)&ix->d_part_off, &ix->off_cap);
+    if (sta != PBA_OK) return sta;
     HIPCHK(hipMemcpyAsync(ix->d_part_off, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(cnt.p, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));   // cursors
     if (total) {
@@ -528,8 +549,8 @@ int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t
     const int logP = ix->logP;
     const uint32_t P = 1u << logP;
     const uint8_t *d_seq = target->d_packed + target->h_off[seq];
-    DevBuf cnt;
-    hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
+    BufRef cnt;
+    hipError_t e = pool_reserve(ctx, POOL_IX_CNT, sizeof(uint32_t) * (P + 1), &cnt.p) == PBA_OK ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
     if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
     (void)hipEventRecord(ctx->ev[0], ctx->stream);
@@ -593,8 +614,8 @@ int pba_index_from_entries(pba_ctx *ctx, const void *d_entries, uint64_t n, uint
     ix->logP = index_logp(n);
     const int logP = ix->logP;
     const uint32_t P = 1u << logP;
-    DevBuf cnt;
-    hipError_t e = hipMalloc(&cnt.p, sizeof(uint32_t) * (P + 1));
+    BufRef cnt;
+    hipError_t e = pool_reserve(ctx, POOL_IX_CNT, sizeof(uint32_t) * (P + 1), &cnt.p) == PBA_OK ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
     if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
     const uint32_t grid = (uint32_t)((n + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS);

@@ -47,6 +47,9 @@ struct pba_ctx {
     // array of a million-read target range cost more than the kernels that fill it; the 4 MB of per-read rows of a
     // locate step cost 1 ms of a 50 ms step): grown on demand (pool_reserve), released by pba_ctx_trim or with the ctx.
     struct { void *p; size_t cap; } pool[16];
+    // the entry / offset arrays of the index destroyed last, for the next build (a step of the locate loop builds and drops
+    // one index: the hipFree / hipMalloc pair of its 40 MB cost 0.2 ms of a 48 ms step)
+    struct { void *ent; size_t ent_cap; void *off; size_t off_cap; } ix_cache;
     pba_profile prof;
     char err[512];
 };
@@ -71,6 +74,7 @@ struct pba_seqs {
 
 struct pba_index {
     pba_ctx *ctx;
+    size_t ent_cap, off_cap;     // bytes allocated behind d_ent / d_part_off
     uint32_t mask, seq_len, visited, nhead;
     int32_t tail_top;
     int mode, logP;

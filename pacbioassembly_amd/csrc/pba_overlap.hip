@@ -98,6 +98,7 @@ void pba_probe_table_destroy(pba_probe_table *t) {
     if (t->T.pid) (void)hipFree(t->T.pid);
     if (t->T.pkey) (void)hipFree(t->T.pkey);
     if (t->T.presence) (void)hipFree(t->T.presence);
+    if (t->T.rec) (void)hipFree(t->T.rec);
     delete t;
 }
 
@@ -163,6 +164,9 @@ int pba_probe_table_create(pba_ctx *ctx, const void *d_probe_entries, uint64_t n
         if (t->hashed) hipLaunchKernelGGL(k_pt_fill<true>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T, d_cursor.as<uint32_t>(), t->t2);
         else hipLaunchKernelGGL(k_pt_fill<false>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T, d_cursor.as<uint32_t>(), t->t2);
     }
+    HIPCHK(hipMalloc((void **)&T.rec, sizeof(uint2) * (B + 2)));
+    HIPCHK(hipMemsetAsync(T.rec + B, 0, sizeof(uint2) * 2, ctx->stream));
+    hipLaunchKernelGGL(k_pt_pack, dim3((uint32_t)((B + 1 + 255) / 256)), dim3(256), 0, ctx->stream, T, B + 1, total);
     (void)hipEventRecord(ctx->ev[1], ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
