@@ -129,59 +129,6 @@ k_pt_pack(ProbeTab T, uint64_t n_buckets_plus_1, uint32_t n_entries) {
     T.rec[b] = make_uint2(s, s < n_entries ? T.pid[s] : 0u);
 }
 
-// In-place inclusive scan of a[0 .. n) in three launches: tiles of PBA_SCAN_TILE per workgroup, the tile sums by one
-// workgroup, the carry-in added back.  (2^24 - 2^26 bucket counters, once per probe table.)
-#define PBA_SCAN_TILE 2048
-static __global__ void __launch_bounds__(256)
-k_scan_tiles(uint32_t *a, uint64_t n, uint32_t *tile_sum) {
-    __shared__ uint32_t wsum[4];
-    const uint64_t base = (uint64_t)blockIdx.x * PBA_SCAN_TILE + (uint64_t)threadIdx.x * 8;
-    uint32_t v[8], run = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? a[base + k] : 0u; run += v[k]; v[k] = run; }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = run;                                  // inclusive scan of the per-thread sums across the wavefront
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t carry = inc - run;
-    for (int k = 0; k < w; ++k) carry += wsum[k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] = v[k] + carry;
-    if (threadIdx.x == 255) tile_sum[blockIdx.x] = carry + run;
-}
-static __global__ void __launch_bounds__(1024)
-k_scan_sums(uint32_t *tile_sum, uint32_t n_tiles) {      // one workgroup, exclusive scan in place
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < n_tiles; b0 += 1024) {
-        const uint32_t i = b0 + threadIdx.x;
-        const uint32_t x = i < n_tiles ? tile_sum[i] : 0u;
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        uint32_t inc = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t c = carry_s;
-        for (int k = 0; k < w; ++k) c += wsum[k];
-        if (i < n_tiles) tile_sum[i] = c + inc - x;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = c + inc;
-        __syncthreads();
-    }
-}
-static __global__ void __launch_bounds__(256)
-k_scan_add(uint32_t *a, uint64_t n, const uint32_t *tile_pre) {
-    const uint32_t c = tile_pre[blockIdx.x];
-    const uint64_t base = (uint64_t)blockIdx.x * PBA_SCAN_TILE + (uint64_t)threadIdx.x * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] += c;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // The scan: one workgroup per target, every thread takes 16 consecutive positions from ONE 8-byte load of packed bases
 // (0.25 B per position, the algorithmic read) and looks their keys up with all 16 loads of a stage in flight at once --

@@ -117,6 +117,7 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (auto &b : ctx->pool) if (b.p) (void)hipFree(b.p);
     if (ctx->ix_cache.ent) (void)hipFree(ctx->ix_cache.ent);
+    if (ctx->ix_cache.ent2) (void)hipFree(ctx->ix_cache.ent2);
     if (ctx->ix_cache.off) (void)hipFree(ctx->ix_cache.off);
     delete ctx;
 }
@@ -127,6 +128,7 @@ int pba_ctx_trim(pba_ctx *ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto &b : ctx->pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     if (ctx->ix_cache.ent) (void)hipFree(ctx->ix_cache.ent);
+    if (ctx->ix_cache.ent2) (void)hipFree(ctx->ix_cache.ent2);
     if (ctx->ix_cache.off) (void)hipFree(ctx->ix_cache.off);
     memset(&ctx->ix_cache, 0, sizeof ctx->ix_cache);
     if (ctx->d_scratch) { (void)hipFree(ctx->d_scratch); ctx->d_scratch = nullptr; ctx->scratch_bytes = 0; }
@@ -473,9 +475,10 @@ static uint32_t seg_grid(const ScanSeg &sg) {
     return (uint32_t)((chunks + PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS - 1) / (PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS));
 }
 
+// partitions of 1 024 .. 2 048 entries on average
 static int index_logp(uint64_t n) {
     int logP = 0;
-    while (logP < PBA_IX_MAX_LOGP && (n >> logP) > 1024) ++logP;
+    while (logP < PBA_IX_MAX_LOGP && (n >> logP) > PBA_IX_PART_AVG) ++logP;
     return logP;
 }
 
@@ -489,46 +492,125 @@ static pba_index *index_new(pba_ctx *ctx, uint32_t mask, uint32_t len, int mode,
     return ix;
 }
 
-// counts are in cnt (device, P+1 u32): turn them into offsets, allocate the entry array, let `scatter`
-// fill it (cnt then holds the cursors), sort every partition
-static int index_finish(pba_ctx *ctx, pba_index *ix, BufRef &cnt, const std::function<void()> &scatter) {
-    const uint32_t P = 1u << ix->logP;
-    std::vector<uint32_t> h_cnt(P + 1, 0), h_off(P + 1, 0);
-    HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, ctx->stream));
+// in-place inclusive scan of a[0 .. n) on the stream (seed_index.h: k_scan_*); tiles: scratch of n / PBA_SCAN_TILE + 1 u32
+static void scan_inclusive(pba_ctx *ctx, uint32_t *a, uint64_t n, uint32_t *tiles) {
+    const uint32_t n_tiles = (uint32_t)((n + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, a, n, tiles);
+    if (n_tiles > 1) {
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, tiles, n_tiles);
+        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, a, n, tiles);
+    }
+}
+
+// The partition levels and the sort.  n_upper: an upper bound of the entries (positions visited / slots of the gathered
+// list).  level1(bits, cnt1, cursor, dst): dst == nullptr -> add the sizes of the 2^bits level-1 bins to cnt1[bin];
+// else scatter the entries into dst through cursor[bin].  from_list (nullable): the exchange form, whose level 1 runs
+// through the generic level kernels on this flat list (all-ones entries = padding).
+static int index_levels(pba_ctx *ctx, pba_index *ix, uint64_t n_upper, const uint64_t *from_list,
+                        const std::function<void(int, uint32_t *, uint32_t *, uint64_t *)> &level1) {
+    if (n_upper > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "more than 2^32 index entries");
+    ix->logP = index_logp(n_upper);
+    const int logP = ix->logP, n_levels = std::max(1, (logP + PBA_IX_LVL_BITS - 1) / PBA_IX_LVL_BITS);
+    const uint64_t P = 1ull << logP;
+    tu_attrs();
+    // device arrays: two entry buffers (the levels ping-pong; the last one written becomes the index's), the offsets of
+    // every level (2^depth + 1 each), cursors, tile tables, scan scratch
+    void *ent[2] = {nullptr, nullptr};
+    size_t ent_cap[2] = {0, 0};
+    int sta = ix_alloc(ctx, &ctx->ix_cache.ent, &ctx->ix_cache.ent_cap, sizeof(uint64_t) * (n_upper + 1), &ent[0], &ent_cap[0]);
+    if (sta != PBA_OK) return sta;
+    ix->d_ent = (uint64_t *)ent[0]; ix->ent_cap = ent_cap[0];                      // (the index owns it from here on: error paths free it with the index)
+    // (the second entry buffer comes from the ctx's one-deep cache of index arrays too when it holds one -- in a loop of
+    // build / destroy the two buffers just swap roles -- and goes back there; offsets and work tables are pooled)
+    BufRef offs, work;
+    size_t second_cap = 0;
+    void *second = nullptr;
+    if (n_levels > 1) {
+        sta = ix_alloc(ctx, &ctx->ix_cache.ent2, &ctx->ix_cache.ent2_cap, sizeof(uint64_t) * (n_upper + 1), &second, &second_cap);
+        if (sta != PBA_OK) return sta;
+        ent[1] = second; ent_cap[1] = second_cap;
+    }
+    struct Spare { pba_ctx *ctx; void **p; size_t *cap; ~Spare() {          // the buffer the index does not keep: back to the cache
+        if (*p) { if (!ctx->ix_cache.ent2) { ctx->ix_cache.ent2 = *p; ctx->ix_cache.ent2_cap = *cap; } else (void)hipFree(*p); }
+    } } spare{ctx, &second, &second_cap};
+    POOL(POOL_IX_OFFS, sizeof(uint32_t) * (2 * P + 2 * (uint64_t)n_levels + 8), offs.p);             // sum over the levels < 2 P + levels
+    POOL(POOL_IX_WORK, sizeof(uint32_t) * (3 * P + 64), work.p);                                     // cursor | tile_pre | scan scratch
+    uint32_t *const cursor = work.as<uint32_t>(), *const tile_pre = cursor + P + 8, *const tiles = tile_pre + P + 8;
+    uint32_t *off_prev = nullptr, *off_k = offs.as<uint32_t>();
+    uint32_t *const list_off = offs.as<uint32_t>() + 2 * P + 2 * (uint64_t)n_levels + 4;    // {0, n}: the one group of a gathered list
+    int done = 0, cur = 0;
+    (void)hipEventRecord(ctx->ev[0], ctx->stream);
+    for (int k = 0; k < n_levels; ++k) {
+        const int bits = (logP - done + (n_levels - k) - 1) / (n_levels - k);      // the remaining bits, split evenly
+        const uint64_t bins = 1ull << (done + bits);
+        HIPCHK(hipMemsetAsync(off_k, 0, sizeof(uint32_t) * (bins + 1), ctx->stream));
+        LvlSrc L;
+        uint32_t grid = 0;
+        if (k > 0 || from_list) {
+            // tiles of the groups: tile_pre[g] = tiles of the groups before g
+            L.src = k == 0 ? from_list : (const uint64_t *)ent[cur ^ 1]; L.done = done; L.bits = bits;
+            L.n_groups = (uint32_t)(1ull << done);
+            if (k == 0) {                                                          // one group: the whole list
+                const uint32_t h[2] = {0u, (uint32_t)n_upper}, t[2] = {0u, (uint32_t)((n_upper + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS)};
+                HIPCHK(hipMemcpyAsync(list_off, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(hipMemcpyAsync(tile_pre, t, sizeof t, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));                         // (h, t are locals)
+                L.off_prev = list_off;
+            } else {
+                HIPCHK(hipMemsetAsync(tile_pre, 0, sizeof(uint32_t), ctx->stream));
+                hipLaunchKernelGGL(k_lvl_tiles, dim3((L.n_groups + 255) / 256), dim3(256), 0, ctx->stream, off_prev, L.n_groups, tile_pre + 1);
+                scan_inclusive(ctx, tile_pre + 1, L.n_groups, tiles);
+                L.off_prev = off_prev;
+            }
+            L.tile_pre = tile_pre;
+            grid = (uint32_t)(n_upper / PBA_IX_TILE_POS + L.n_groups + 1);          // >= the tiles there are; the rest exit
+        }
+        if (grid) hipLaunchKernelGGL(k_lvl_count, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, L, off_k + 1);
+        else level1(bits, off_k + 1, nullptr, nullptr);
+        scan_inclusive(ctx, off_k + 1, bins, tiles);
+        HIPCHK(hipMemcpyAsync(cursor, off_k, sizeof(uint32_t) * bins, hipMemcpyDeviceToDevice, ctx->stream));
+        if (grid) hipLaunchKernelGGL(k_lvl_scatter, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, L, cursor, (uint64_t *)ent[cur]);
+        else level1(bits, nullptr, cursor, (uint64_t *)ent[cur]);
+        off_prev = off_k; off_k += bins + 1; done += bits; cur ^= 1;
+    }
+    cur ^= 1;                                                                      // the buffer the last level wrote
+    // totals: entries, the largest partition the LDS sort takes, partitions beyond it
+    uint32_t *const stat = tiles;                                                  // (the scan scratch is free again)
+    HIPCHK(hipMemsetAsync(stat, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_part_max, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, ctx->stream, off_prev, (uint32_t)P, stat);
+    uint32_t h_stat[2] = {0, 0}, total = 0;
+    HIPCHK(hipMemcpyAsync(h_stat, stat, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&total, off_prev + P, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
-    uint64_t total = 0;
-    for (uint32_t p = 0; p < P; ++p) { h_off[p] = (uint32_t)total; total += h_cnt[p]; }
-    if (total > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "more than 2^32 index entries");
-    h_off[P] = (uint32_t)total;
     ix->n_entries = total;
-    int sta = ix_alloc(ctx, &ctx->ix_cache.ent, &ctx->ix_cache.ent_cap, sizeof(uint64_t) * (total + 1), (void **)&ix->d_ent, &ix->ent_cap);
-    if (sta == PBA_OK) sta = ix_alloc(ctx, &ctx->ix_cache.off, &ctx->ix_cache.off_cap, sizeof(uint32_t) * (P + 1), (void **)&ix->d_part_off, &ix->off_cap);
+    sta = ix_alloc(ctx, &ctx->ix_cache.off, &ctx->ix_cache.off_cap, sizeof(uint32_t) * (P + 1), (void **)&ix->d_part_off, &ix->off_cap);
     if (sta != PBA_OK) return sta;
-    HIPCHK(hipMemcpyAsync(ix->d_part_off, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(cnt.p, h_off.data(), sizeof(uint32_t) * (P + 1), hipMemcpyHostToDevice, ctx->stream));   // cursors
+    HIPCHK(hipMemcpyAsync(ix->d_part_off, off_prev, sizeof(uint32_t) * (P + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    // the index keeps the buffer the last level wrote; the other one is the temporary
+    if (cur == 1) { ix->d_ent = (uint64_t *)ent[1]; ix->ent_cap = ent_cap[1]; second = ent[0]; second_cap = ent_cap[0]; }   // (the first is the spare now)
     if (total) {
-        tu_attrs();
-        scatter();
-        // LDS by need, not by capacity: a 2 048-entry partition takes 16 KB, so ten workgroups share a CU
-        // instead of one (k_part_sort was 0.61 ms of a 0.77 ms build at 5 Mb with the full 128 KB request)
-        uint32_t biggest = 2;
-        for (uint32_t p = 0; p < P; ++p)
-            if (h_cnt[p] <= PBA_IX_LDS_SORT_CAP) biggest = std::max(biggest, h_cnt[p]);
+        // LDS by need, not by capacity: a 2 048-entry partition takes 16 KB, so ten workgroups share a CU instead of one
         uint32_t pow2 = 2;
-        while (pow2 < biggest) pow2 <<= 1;
-        hipLaunchKernelGGL(k_part_sort, dim3(P), dim3(256), sizeof(uint64_t) * pow2, ctx->stream, ix->d_ent,
-                           ix->d_part_off);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipGetLastError());
-        for (uint32_t p = 0; p < P; ++p)
-            if (h_cnt[p] > PBA_IX_LDS_SORT_CAP) {
-                int st = sort_partition_global(ctx, ix->d_ent + h_off[p], h_cnt[p]);
-                if (st != PBA_OK) return st;
-            }
+        while (pow2 < h_stat[0]) pow2 <<= 1;
+        for (uint64_t p0 = 0; p0 < P; p0 += 0x40000000ull)
+            hipLaunchKernelGGL(k_part_sort, dim3((uint32_t)std::min<uint64_t>(P - p0, 0x40000000ull)), dim3(pow2 >= 4096 ? 1024 : 256),
+                               sizeof(uint64_t) * pow2, ctx->stream, ix->d_ent, ix->d_part_off + p0);
+        if (h_stat[1]) {                                                           // low-complexity targets: partitions beyond the LDS sort
+            std::vector<uint32_t> h_off(P + 1);
+            HIPCHK(hipMemcpyAsync(h_off.data(), ix->d_part_off, sizeof(uint32_t) * (P + 1), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            for (uint64_t q = 0; q < P; ++q)
+                if (h_off[q + 1] - h_off[q] > PBA_IX_LDS_SORT_CAP) {
+                    int st = sort_partition_global(ctx, ix->d_ent + h_off[q], h_off[q + 1] - h_off[q]);
+                    if (st != PBA_OK) return st;
+                }
+        }
     }
     (void)hipEventRecord(ctx->ev[1], ctx->stream);
     (void)hipEventSynchronize(ctx->ev[1]);
+    HIPCHK(hipGetLastError());
     (void)hipEventElapsedTime(&ctx->prof.index_ms, ctx->ev[0], ctx->ev[1]);
     return PBA_OK;
 }
@@ -545,22 +627,14 @@ int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t
     if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
     uint64_t npos = 0;
     for (int s = 0; s < v.nseg; ++s) npos += v.segs[s].hi - v.segs[s].lo;
-    ix->logP = index_logp(npos);
-    const int logP = ix->logP;
-    const uint32_t P = 1u << logP;
     const uint8_t *d_seq = target->d_packed + target->h_off[seq];
-    BufRef cnt;
-    hipError_t e = pool_reserve(ctx, POOL_IX_CNT, sizeof(uint32_t) * (P + 1), &cnt.p) == PBA_OK ? hipSuccess : hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
-    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
-    (void)hipEventRecord(ctx->ev[0], ctx->stream);
-    for (int s = 0; s < v.nseg; ++s)
-        hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
-                           mask, v.segs[s], logP, cnt.as<uint32_t>());
-    int st = index_finish(ctx, ix, cnt, [&]() {
-        for (int s = 0; s < v.nseg; ++s)
-            hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq,
-                               len, mask, v.segs[s], logP, cnt.as<uint32_t>(), ix->d_ent);
+    int st = index_levels(ctx, ix, npos, nullptr, [&](int bits, uint32_t *cnt1, uint32_t *cursor, uint64_t *dst) {
+        for (int s = 0; s < v.nseg; ++s) {
+            if (!dst) hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+                                         mask, v.segs[s], bits, cnt1);
+            else hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+                                    mask, v.segs[s], bits, cursor, dst);
+        }
     });
     if (st != PBA_OK) { pba_index_destroy(ix); return st; }
     *out = ix;
@@ -611,22 +685,7 @@ int pba_index_from_entries(pba_ctx *ctx, const void *d_entries, uint64_t n, uint
     const VisitPlan v = visit_plan(seq_len, mode);
     pba_index *ix = index_new(ctx, mask, seq_len, mode, v);
     if (!ix) PBA_FAIL(PBA_E_NOMEM, "pba_index");
-    ix->logP = index_logp(n);
-    const int logP = ix->logP;
-    const uint32_t P = 1u << logP;
-    BufRef cnt;
-    hipError_t e = pool_reserve(ctx, POOL_IX_CNT, sizeof(uint32_t) * (P + 1), &cnt.p) == PBA_OK ? hipSuccess : hipErrorOutOfMemory;
-    if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(uint32_t) * (P + 1), ctx->stream);
-    if (e != hipSuccess) { pba_index_destroy(ix); return ctx_fail(ctx, PBA_E_HIP, "index alloc", e); }
-    const uint32_t grid = (uint32_t)((n + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS);
-    (void)hipEventRecord(ctx->ev[0], ctx->stream);
-    if (grid)
-        hipLaunchKernelGGL(k_ent_count, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, (const uint64_t *)d_entries, n,
-                           logP, cnt.as<uint32_t>());
-    int st = index_finish(ctx, ix, cnt, [&]() {
-        hipLaunchKernelGGL(k_ent_scatter, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, (const uint64_t *)d_entries,
-                           n, logP, cnt.as<uint32_t>(), ix->d_ent);
-    });
+    int st = index_levels(ctx, ix, n, (const uint64_t *)d_entries, [](int, uint32_t *, uint32_t *, uint64_t *) {});
     if (st != PBA_OK) { pba_index_destroy(ix); return st; }
     *out = ix;
     return PBA_OK;

@@ -49,7 +49,7 @@ struct pba_ctx {
     struct { void *p; size_t cap; } pool[16];
     // the entry / offset arrays of the index destroyed last, for the next build (a step of the locate loop builds and drops
     // one index: the hipFree / hipMalloc pair of its 40 MB cost 0.2 ms of a 48 ms step)
-    struct { void *ent; size_t ent_cap; void *off; size_t off_cap; } ix_cache;
+    struct { void *ent; size_t ent_cap; void *off; size_t off_cap; void *ent2; size_t ent2_cap; } ix_cache;
     pba_profile prof;
     char err[512];
 };
@@ -104,7 +104,7 @@ static const size_t kSlack = 1024;              // readable bytes before the fir
 
 // pool slots
 enum { POOL_OVL_CAND = 0, POOL_OVL_TMP, POOL_OVL_ITEMS, POOL_OVL_REDO, POOL_OVL_REDO_IN, POOL_OVL_OUT, POOL_OVL_SMALL,
-       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_CNT };
+       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_OFFS, POOL_IX_WORK };
 // a buffer of at least `bytes` in pool slot `slot` (contents undefined); grows by reallocation with 1/8 headroom
 static inline int pool_reserve(pba_ctx *ctx, int slot, size_t bytes, void **out) {
     if (ctx->pool[slot].cap < bytes) {

@@ -11,15 +11,20 @@
 // inside a key, by insertion order -- exactly the order a list<int> hands back.  A probe hashes
 // to its partition and binary-searches the key's run.
 //
-// Build = coalesced scan of the 2-bit packed bases (0.25 B/base read), per-workgroup LDS
-// histogram of the hash partitions, one global reservation per (workgroup, partition), scatter,
-// then one workgroup per partition sorts its entries in LDS.
+// Build = coalesced scan of the 2-bit packed bases (0.25 B/base read), then an MSD partition on the bits of the key's
+// hash, at most PBA_IX_LVL_BITS per level: per-workgroup LDS histogram of the level's bins, one global reservation per
+// (workgroup, bin), scatter -- a workgroup's 16 384-entry tile leaves >= 64 entries (512 contiguous bytes) in every bin of a
+// level, so the partition writes whole lines whatever the size of the index (one level with 4 096 bins wrote 32-byte
+// pieces: 3.8x write amplification, and nothing beyond 2^12 partitions: a 500 Mb target took 1.7 s) -- and finally one
+// workgroup per partition sorts its ~2 048 entries in LDS.
 #ifndef PBA_SEED_INDEX_H
 #define PBA_SEED_INDEX_H
 
 #include "dev_common.h"
 
-#define PBA_IX_MAX_LOGP 12                 // <= 4096 partitions: two u32 LDS tables = 32 KB
+#define PBA_IX_MAX_LOGP 24                 // partitions of ~2 048 entries for up to 2^32 entries (minus the average)
+#define PBA_IX_LVL_BITS 8                  // hash bits one partition level resolves (256 bins: two u32 LDS tables = 2 KB)
+#define PBA_IX_PART_AVG 2048               // entries per partition the builder aims at (1 024 .. 2 048)
 #define PBA_IX_LDS_SORT_CAP 16384          // entries one workgroup sorts in LDS (128 KB)
 #define PBA_IX_TILE_THREADS 256
 #define PBA_IX_TILE_ITERS 4
@@ -130,11 +135,12 @@ __device__ __forceinline__ uint32_t chunk_key(uint64_t be, uint32_t k, uint32_t 
     return __builtin_bswap32(w) & mask;
 }
 
-// pass 1: partition sizes
+// level 1 from the packed bases: bin = the top `bits` bits of the key's hash
+// cnt1 points one slot past the bin's offset slot (counts are scanned in place into offsets)
 static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
-k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int logP, uint32_t *part_cnt) {
-    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
-    const uint32_t P = 1u << logP;
+k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int bits, uint32_t *cnt1) {
+    __shared__ uint32_t hist[1 << PBA_IX_LVL_BITS];
+    const uint32_t P = 1u << bits;
     for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
     __syncthreads();
     const uint32_t chunk0 = sg.lo >> 4;
@@ -147,21 +153,20 @@ k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int lo
             const uint32_t pos = chunk * 16 + k;
             if (pos < sg.lo || pos >= sg.hi) continue;
             const uint32_t key = chunk_key(be, k, pos, len, mask);
-            if (key) atomicAdd(&hist[ix_part(key, logP)], 1u);
+            if (key) atomicAdd(&hist[ix_part(key, bits)], 1u);
         }
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
-        if (hist[p]) atomicAdd(&part_cnt[p], hist[p]);
+        if (hist[p]) atomicAdd(&cnt1[p], hist[p]);
 }
 
-// pass 2: scatter entries into their partitions (order inside a partition is fixed by the sort)
+// ... and the entries into their level-1 bins (order inside a bin does not matter: the partitions are sorted at the end)
 static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
-k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int logP, uint32_t *part_cursor,
-               uint64_t *ent) {
-    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
-    __shared__ uint32_t base[1 << PBA_IX_MAX_LOGP];
-    const uint32_t P = 1u << logP;
+k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int bits, uint32_t *cursor, uint64_t *dst) {
+    __shared__ uint32_t hist[1 << PBA_IX_LVL_BITS];
+    __shared__ uint32_t base[1 << PBA_IX_LVL_BITS];
+    const uint32_t P = 1u << bits;
     for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
     __syncthreads();
     const uint32_t chunk0 = sg.lo >> 4;
@@ -176,13 +181,13 @@ k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int 
             const uint32_t pos = chunk * 16 + k;
             if (pos < sg.lo || pos >= sg.hi) continue;
             const uint32_t key = chunk_key(be[it], k, pos, len, mask);
-            if (key) atomicAdd(&hist[ix_part(key, logP)], 1u);
+            if (key) atomicAdd(&hist[ix_part(key, bits)], 1u);
         }
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
         const uint32_t n = hist[p];
-        base[p] = n ? atomicAdd(&part_cursor[p], n) : 0u;
+        base[p] = n ? atomicAdd(&cursor[p], n) : 0u;
         hist[p] = 0;
     }
     __syncthreads();
@@ -195,12 +200,94 @@ k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int 
             if (pos < sg.lo || pos >= sg.hi) continue;
             const uint32_t key = chunk_key(be[it], k, pos, len, mask);
             if (!key) continue;
-            const uint32_t p = ix_part(key, logP);
+            const uint32_t p = ix_part(key, bits);
             const uint32_t slot = base[p] + atomicAdd(&hist[p], 1u);
             const uint32_t ord = sg.ord0 + (sg.descending ? sg.hi - 1 - pos : pos - sg.lo);
-            ent[slot] = (uint64_t)key << 32 | ord;
+            dst[slot] = (uint64_t)key << 32 | ord;
         }
     }
+}
+
+// ---- a further level: the entries, grouped by the top `done` bits of their hash (off_prev: the groups' offsets), are
+// split by the next `bits` bits.  A workgroup takes one tile of PBA_IX_TILE_POS entries of one group (tile_pre: tiles of
+// the groups before it).  Also level 1 of the exchange form: one group = the gathered list, all-ones entries = padding.
+struct LvlSrc {
+    const uint64_t *src;
+    const uint32_t *off_prev, *tile_pre;
+    uint32_t n_groups;
+    int done, bits;
+};
+__device__ __forceinline__ bool lvl_tile(const LvlSrc &L, uint32_t &group, uint32_t &lo, uint32_t &hi) {
+    uint32_t a = 0, b = L.n_groups;                     // last group g with tile_pre[g] <= blockIdx.x
+    if (blockIdx.x >= L.tile_pre[L.n_groups]) return false;
+    while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (L.tile_pre[mid] <= blockIdx.x) a = mid; else b = mid;
+    }
+    group = a;
+    lo = L.off_prev[a] + (blockIdx.x - L.tile_pre[a]) * PBA_IX_TILE_POS;
+    hi = min(L.off_prev[a + 1], lo + (uint32_t)PBA_IX_TILE_POS);
+    return true;
+}
+// the entry's bin inside its group: the `bits` hash bits below the top `done`
+__device__ __forceinline__ uint32_t lvl_bin(const LvlSrc &L, uint64_t e) {
+    return L.bits ? ((((uint32_t)(e >> 32)) * 0x9E3779B1u) >> (32 - L.done - L.bits)) & ((1u << L.bits) - 1u) : 0u;
+}
+static __global__ void __launch_bounds__(256)
+k_lvl_tiles(const uint32_t *off_prev, uint32_t n_groups, uint32_t *ntiles1) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_groups) ntiles1[g] = (off_prev[g + 1] - off_prev[g] + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS;
+}
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_lvl_count(LvlSrc L, uint32_t *cnt1) {
+    __shared__ uint32_t hist[1 << PBA_IX_LVL_BITS];
+    uint32_t g, lo, hi;
+    if (!lvl_tile(L, g, lo, hi)) return;
+    const uint32_t P = 1u << L.bits;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint64_t e = L.src[i];
+        if (e != ~0ull) atomicAdd(&hist[lvl_bin(L, e)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
+        if (hist[p]) atomicAdd(&cnt1[(g << L.bits) + p], hist[p]);
+}
+static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
+k_lvl_scatter(LvlSrc L, uint32_t *cursor, uint64_t *dst) {
+    __shared__ uint32_t hist[1 << PBA_IX_LVL_BITS];
+    __shared__ uint32_t base[1 << PBA_IX_LVL_BITS];
+    uint32_t g, lo, hi;
+    if (!lvl_tile(L, g, lo, hi)) return;
+    const uint32_t P = 1u << L.bits;
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint64_t e = L.src[i];
+        if (e != ~0ull) atomicAdd(&hist[lvl_bin(L, e)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+        const uint32_t c = hist[p];
+        base[p] = c ? atomicAdd(&cursor[(g << L.bits) + p], c) : 0u;
+        hist[p] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint64_t e = L.src[i];
+        if (e == ~0ull) continue;
+        const uint32_t p = lvl_bin(L, e);
+        dst[base[p] + atomicAdd(&hist[p], 1u)] = e;
+    }
+}
+// the largest partition (for the LDS the sort asks for) and how many outgrow the LDS sort
+static __global__ void __launch_bounds__(256)
+k_part_max(const uint32_t *part_off, uint32_t P, uint32_t *out2) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t n = part_off[p + 1] - part_off[p];
+    if (n <= PBA_IX_LDS_SORT_CAP) atomicMax(&out2[0], n); else atomicAdd(&out2[1], 1u);
 }
 
 // ---- multi-GPU exchange form: a rank scans its slice of the visiting order into a flat entry list ...
@@ -249,54 +336,57 @@ k_seed_emit(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, uint64_
     }
 }
 
-// ... and every rank builds the partitions from the gathered list (all-ones entries are padding)
-static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
-k_ent_count(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cnt) {
-    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
-    const uint32_t P = 1u << logP;
-    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+// In-place inclusive scan of a[0 .. n) in three launches: tiles of PBA_SCAN_TILE per workgroup, the tile sums by one
+// workgroup, the carry-in added back.  (2^24 - 2^26 bucket counters, once per probe table.)
+#define PBA_SCAN_TILE 2048
+static __global__ void __launch_bounds__(256)
+k_scan_tiles(uint32_t *a, uint64_t n, uint32_t *tile_sum) {
+    __shared__ uint32_t wsum[4];
+    const uint64_t base = (uint64_t)blockIdx.x * PBA_SCAN_TILE + (uint64_t)threadIdx.x * 8;
+    uint32_t v[8], run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? a[base + k] : 0u; run += v[k]; v[k] = run; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = run;                                  // inclusive scan of the per-thread sums across the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * PBA_IX_TILE_POS;
-    for (uint32_t i = threadIdx.x; i < PBA_IX_TILE_POS; i += blockDim.x) {
-        const uint64_t q = base + i;
-        if (q >= n) break;
-        const uint64_t e = in[q];
-        if (e != ~0ull) atomicAdd(&hist[ix_part((uint32_t)(e >> 32), logP)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
-        if (hist[p]) atomicAdd(&part_cnt[p], hist[p]);
+    uint32_t carry = inc - run;
+    for (int k = 0; k < w; ++k) carry += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] = v[k] + carry;
+    if (threadIdx.x == 255) tile_sum[blockIdx.x] = carry + run;
 }
-
-static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
-k_ent_scatter(const uint64_t *in, uint64_t n, int logP, uint32_t *part_cursor, uint64_t *ent) {
-    __shared__ uint32_t hist[1 << PBA_IX_MAX_LOGP];
-    __shared__ uint32_t base[1 << PBA_IX_MAX_LOGP];
-    const uint32_t P = 1u << logP;
-    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
+static __global__ void __launch_bounds__(1024)
+k_scan_sums(uint32_t *tile_sum, uint32_t n_tiles) {      // one workgroup, exclusive scan in place
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    const uint64_t b0 = (uint64_t)blockIdx.x * PBA_IX_TILE_POS;
-    for (uint32_t i = threadIdx.x; i < PBA_IX_TILE_POS; i += blockDim.x) {
-        const uint64_t q = b0 + i;
-        if (q >= n) break;
-        const uint64_t e = in[q];
-        if (e != ~0ull) atomicAdd(&hist[ix_part((uint32_t)(e >> 32), logP)], 1u);
+    for (uint32_t b0 = 0; b0 < n_tiles; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t x = i < n_tiles ? tile_sum[i] : 0u;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t c = carry_s;
+        for (int k = 0; k < w; ++k) c += wsum[k];
+        if (i < n_tiles) tile_sum[i] = c + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = c + inc;
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
-        const uint32_t c = hist[p];
-        base[p] = c ? atomicAdd(&part_cursor[p], c) : 0u;
-        hist[p] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < PBA_IX_TILE_POS; i += blockDim.x) {
-        const uint64_t q = b0 + i;
-        if (q >= n) break;
-        const uint64_t e = in[q];
-        if (e == ~0ull) continue;
-        const uint32_t p = ix_part((uint32_t)(e >> 32), logP);
-        ent[base[p] + atomicAdd(&hist[p], 1u)] = e;
-    }
+}
+static __global__ void __launch_bounds__(256)
+k_scan_add(uint32_t *a, uint64_t n, const uint32_t *tile_pre) {
+    const uint32_t c = tile_pre[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * PBA_SCAN_TILE + (uint64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] += c;
 }
 
 // pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
