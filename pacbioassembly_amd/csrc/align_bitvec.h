@@ -146,7 +146,22 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 //            the reference's b (`swap_roles`): set = the reference's INSERT, clear = its DELETE, for cells whose
 //            parent is not diagonal (INSERT is tried first and wins the tie, seq_aligner.h:167-173)
 // at tr[((t-1) * NB + nb) * 128 + 2 * lane + word]: one 8-byte store per lane, 512 contiguous bytes per instruction.
-template <int NB, bool TRACE = false>
+// TRACE == 2: instead, checkpoints -- at the start of every 32-step chunk the lane's Pv / Mv words, its superblock and window
+// state and the two hand-off masks go to tr (bv_ck_words per chunk, 1/25 of the streamed words); the walk re-runs one
+// chunk at a time from its checkpoint into LDS (align_bvtrace.h: bitvec_rerun).
+#define PBA_BV_CK_WORDS(nb) ((nb) * 128 + 128)
+template <int NB>
+__device__ __forceinline__ void bv_ckpt_store(uint32_t *tr, int tb, int lane, const uint32_t *Pv, const uint32_t *Mv, int s_cur,
+                                              uint32_t opened, uint64_t hp_last, uint64_t hn_last) {
+    uint32_t *ck = tr + (size_t)((tb - 1) >> 5) * PBA_BV_CK_WORDS(NB);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ck[nb * 128 + lane] = Pv[nb]; ck[nb * 128 + 64 + lane] = Mv[nb]; }
+    ck[NB * 128 + lane] = (uint32_t)s_cur | (opened << 31);
+    if (lane < 4)
+        ck[NB * 128 + 64 + lane] = lane == 0 ? (uint32_t)hp_last : lane == 1 ? (uint32_t)(hp_last >> 32) : lane == 2 ? (uint32_t)hn_last : (uint32_t)(hn_last >> 32);
+}
+
+template <int NB, int TRACE = 0>
 __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
                                            double R, int &best_out, int &besti_out, int &diag_out, uint32_t *tr = nullptr,
                                            bool swap_roles = false) {
@@ -271,7 +286,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
         t_next = min(min(t_evt, t_seg + 1), min(t_dstart, t <= t_hin_end ? t_hin_end + 1 : INT_MAX)); \
       }                                                                               \
       valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);   /* changes only at events: kept as a scalar mask */ \
-      if constexpr (TRACE) st_on = ((__builtin_amdgcn_ballot_w64(opened != 0) >> (lane & 48)) & 0xFFFFull) != 0; \
+      if constexpr (TRACE == 1) st_on = ((__builtin_amdgcn_ballot_w64(opened != 0) >> (lane & 48)) & 0xFFFFull) != 0; \
       ON_EVENT;                                                                       \
     }
 
@@ -317,6 +332,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     bool failed = false;
     for (int tbv = 1; tbv <= t1; tbv += 32) {
         const int tb = __builtin_amdgcn_readfirstlane(tbv);   // (the early exit below makes the compiler treat tbv as divergent)
+        if constexpr (TRACE == 2) bv_ckpt_store<NB>(tr, tb, lane, Pv, Mv, s_cur, opened, hp_last, hn_last);
         load_text(tb);                           // next text planes
         if (failed) break;
         int kend = min(32, t1 - tb + 1);
@@ -332,7 +348,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
             uint32_t d0, php, mhp, eq;
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
             (void)php; (void)mhp; (void)eq;
-            if constexpr (TRACE) {           // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
+            if constexpr (TRACE == 1) {      // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
                 if (st_on)                   // inside its window (masking lane by lane was measured 1.5x SLOWER: partial lines)
                     PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);
             }
@@ -362,7 +378,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     // ------------------------------------------------------------------ phase 2: the superblocks below row m take the last column
     for (int tb = t1 + 1; tb <= t_end;) {
         const int k0 = (tb - 1) & 31;            // phase 2 starts inside a chunk whose planes are already loaded
-        if (k0 == 0) load_text(tb);
+        if (k0 == 0) {
+            if constexpr (TRACE == 2) bv_ckpt_store<NB>(tr, tb, lane, Pv, Mv, s_cur, opened, hp_last, hn_last);
+            load_text(tb);
+        }
         const int kend = min(32, k0 + (t_end - tb + 1));
         for (int k = k0; k < kend; ++k) {
         const int t = tb - k0 + k;
@@ -374,7 +393,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
             uint32_t d0, php, mhp, eq;
             PBA_BV_BLOCK(nb, php, mhp, d0, eq);
             (void)d0; (void)eq; (void)php; (void)mhp;
-            if constexpr (TRACE) {           // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
+            if constexpr (TRACE == 1) {      // whole 128-byte lines only: a 16-lane group stores when any of its lanes is
                 if (st_on)                   // inside its window (masking lane by lane was measured 1.5x SLOWER: partial lines)
                     PBA_BV_TRP()[nb * 64] = make_uint2(eq | ~d0, swap_roles ? Pv[nb] : php);
             }

@@ -34,6 +34,17 @@ __device__ __host__ inline uint64_t bv_trace_words(int nb, int m, int n, int w) 
     return (uint64_t)(t_end > 0 ? t_end : 0) * (uint64_t)nb * 128u;
 }
 
+// ... and of the checkpoint form (TRACE == 2): one checkpoint per 32-step chunk
+__device__ __host__ inline uint64_t bv_ck_words(int nb, int m, int n, int w) {
+    const int rb = 32 * nb;
+    const long long nr = (long long)m + w < n ? (long long)m + w : n;
+    const long long S = (nr + rb - 1) / rb;
+    const long long t_end = m + S - 1;
+    return (uint64_t)((t_end > 0 ? t_end : 0) / 32 + 2) * (uint64_t)PBA_BV_CK_WORDS(nb);
+}
+#define PBA_BV_TILE_LANES 4                     // lanes of a re-run chunk whose words are kept (the path's lane and the three above it)
+#define PBA_BV_TILE_WORDS(nb) (32 * PBA_BV_TILE_LANES * (nb))     // uint2 per wavefront
+
 // The walk reads what OTHER LANES OF THE SAME WAVEFRONT stored: same CU, same vector L1 (write-through, shared
 // by the CU), so plain loads behind a workgroup-scope fence (the stores have completed) are coherent.  Agent-scope
 // (sc1) loads are not the tool here: they are served past this XCD's L2, which still holds the lines dirty.
@@ -105,16 +116,161 @@ __device__ __forceinline__ void bv_trace_walk(const uint32_t *tr, int &ri, int &
     }
 }
 
+// ---- checkpoint form -------------------------------------------------------------------------------------------------
+// Re-run chunk `chunk` (steps 32*chunk + 1 .. t_last) of the sweep bitvec_pass<NB, 2> made, from its checkpoint: the same
+// steps, the same window opens and closes (a lane's superblock and window state at a step are functions of the geometry;
+// the checkpoint holds where the lane stood), none of the diagonal bookkeeping -- and the two traceback words of every
+// (step, block) of the lanes lb, lb-1, lb-2, lb-3 (mod 64) go to `tile` in LDS:
+//   tile[((t - t0) * PBA_BV_TILE_LANES + ((lb - lane) & 63)) * NB + nb] = { Eq | ~D0,  Ph (or the new Pv when swap_roles) }
+template <int NB>
+__device__ __forceinline__ void bitvec_rerun(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
+                                             const uint32_t *ck_base, int chunk, int t_last, int lb, uint2 *tile, bool swap_roles) {
+    constexpr int RB = 32 * NB;
+    const int lane = threadIdx.x & (PBA_WAVE - 1);
+    m = __builtin_amdgcn_readfirstlane(m); nr = __builtin_amdgcn_readfirstlane(nr);
+    w = __builtin_amdgcn_readfirstlane(w); wleft = __builtin_amdgcn_readfirstlane(wleft);
+    chunk = __builtin_amdgcn_readfirstlane(chunk); t_last = __builtin_amdgcn_readfirstlane(t_last);
+    const int S = (nr + RB - 1) / RB;
+    const int t0 = 32 * chunk + 1;
+    const uint32_t *ck = ck_base + (size_t)chunk * PBA_BV_CK_WORDS(NB);
+    uint32_t Pv[NB], Mv[NB], Plo[NB], Phi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        Pv[nb] = __hip_atomic_load(ck + nb * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        Mv[nb] = __hip_atomic_load(ck + nb * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const uint32_t meta = __hip_atomic_load(ck + NB * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t mk = __hip_atomic_load(ck + NB * 128 + 64 + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint64_t hp_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mk, 0) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mk, 1) << 32;
+    uint64_t hn_last = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mk, 2) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mk, 3) << 32;
+    int s_cur = (int)(meta & 0x7FFFFFFFu);
+    uint32_t opened = meta >> 31;
+    int t_evt, t_close1 = 0, t_hin_end;
+    auto open_superblock = [&]() {              // bitvec_pass: open_superblock, without the diagonal
+        const int base_row = s_cur * RB;
+        if (s_cur < S) {
+            const int lo = max(1, base_row + 1 - wleft), hi = min(m, base_row + RB + w);
+            t_evt = lo + s_cur;
+            t_close1 = hi + s_cur + 1;
+            t_hin_end = s_cur > 0 ? min(m, base_row + w) + s_cur : INT_MIN;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) load_planes32(rowsF, base_row + 32 * nb, Plo[nb], Phi[nb]);
+        } else {
+            t_evt = INT_MAX; t_close1 = INT_MAX; t_hin_end = INT_MIN;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { Plo[nb] = 0; Phi[nb] = 0; }
+        }
+    };
+    open_superblock();
+    if (opened) t_evt = t_close1;               // inside its window: the next event is the close
+    uint32_t wl = 0, wh = 0;
+    auto load_text = [&]() { load_planes32(colsF, t0 - s_cur - 1, wl, wh); };
+    load_text();
+    uint64_t valid = __builtin_amdgcn_ballot_w64(t0 <= t_hin_end);
+    int t_next = min(t_evt, t0 <= t_hin_end ? t_hin_end + 1 : INT_MAX);
+    const int slot = (lb - lane) & (PBA_WAVE - 1);
+    const bool keep = slot < PBA_BV_TILE_LANES;
+    const int kend = min(32, t_last - t0 + 1);
+    for (int k = 0; k < kend; ++k) {
+        const int t = t0 + k;
+        if (__builtin_amdgcn_ballot_w64(t == t_next)) {
+            if (t == t_next) {
+                if (t == t_evt) {
+                    if (opened) { s_cur += PBA_WAVE; opened = 0; open_superblock(); load_text(); }
+                    if (t == t_evt) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; }
+                        opened = 1;
+                        t_evt = t_close1;
+                    }
+                }
+                t_next = min(t_evt, t <= t_hin_end ? t_hin_end + 1 : INT_MAX);
+            }
+            valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);
+        }
+        const uint32_t clo = bit_mask(wl, k), chi = bit_mask(wh, k);
+        uint64_t hp = (((hp_last << 1) | (hp_last >> 63)) & valid) | ~valid;
+        uint64_t hn = ((hn_last << 1) | (hn_last >> 63)) & valid;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const uint32_t Eq = eq_mask(Plo[nb] ^ clo, Phi[nb], chi);
+            const uint32_t pv = Pv[nb], mv = Mv[nb];
+            uint64_t unused;
+            const uint32_t sum = addc_mask(Eq & pv, pv, hn, unused);
+            const uint32_t Xh = (sum ^ pv) | Eq;
+            const uint32_t Ph = mv | ~(Xh | pv);
+            const uint32_t Mh = pv & Xh;
+            const uint32_t D0 = Xh | mv;
+            const uint32_t Ph2 = addc_mask(Ph, Ph, hp, hp);
+            const uint32_t Mh2 = addc_mask(Mh, Mh, hn, hn);
+            Pv[nb] = Mh2 | ~(D0 | Ph2);
+            Mv[nb] = Ph2 & D0;
+            if (keep) tile[(k * PBA_BV_TILE_LANES + slot) * NB + nb] = make_uint2(Eq | ~D0, swap_roles ? Pv[nb] : Ph);
+        }
+        hp_last = hp; hn_last = hn;
+    }
+}
+
+// The walk of the checkpoint form: like bv_trace_walk, but the words of the step a cell sits at come from the LDS tile of
+// its chunk, re-run on demand.  The step of the path never grows on the way back (a diagonal or horizontal move costs one
+// or two steps, a vertical one none), so every chunk is re-run once -- unless the path runs vertically through more
+// lanes than the tile keeps, which re-runs the chunk with the tile moved up.
+template <int NB, class Sink>
+__device__ __forceinline__ void bv_trace_walk_ck(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
+                                                 const uint32_t *ck_base, int t_end, uint2 *tile, int &ri, int &cj, bool swap_roles,
+                                                 Sink &sink) {
+    constexpr int RB = 32 * NB;
+    const int lane = threadIdx.x & (PBA_WAVE - 1);
+    int have_chunk = -1, have_lb = 0;
+    while (ri > 0 && cj > 0) {
+        const int s = (ri - 1) / RB, ln = s & (PBA_WAVE - 1), nb = ((ri - 1) - s * RB) >> 5;
+        const int row_lo = s * RB + nb * 32;               // this word holds rows row_lo+1 .. row_lo+32
+        const int tcur = cj + s;                           // the step the cell was computed at
+        const int chunk = (tcur - 1) >> 5, t0 = 32 * chunk + 1;
+        if (chunk != have_chunk || ((have_lb - ln) & (PBA_WAVE - 1)) >= PBA_BV_TILE_LANES) {
+            __builtin_amdgcn_wave_barrier();               // (earlier reads of the tile are done)
+            bitvec_rerun<NB>(rowsF, nr, colsF, m, wleft, w, ck_base, chunk, min(t0 + 31, t_end), ln, tile, swap_roles);
+            __builtin_amdgcn_wave_barrier();
+            have_chunk = chunk; have_lb = ln;
+        }
+        const int slot = (have_lb - ln) & (PBA_WAVE - 1);
+        const int tt = tcur - lane;                        // lane d looks at the step d before the cell's
+        uint32_t wm = 0, wh = 0;
+        if (tt >= t0) {
+            const uint2 v = tile[((tt - t0) * PBA_BV_TILE_LANES + slot) * NB + nb];
+            wm = v.x;
+            wh = v.y;
+        }
+        const int dmax = tcur - t0;                        // lanes 0 .. dmax hold words of this chunk
+        int d = 0;
+        do {
+            const int bit = (ri - 1) & 31;
+            const uint32_t mbit = ((uint32_t)__builtin_amdgcn_readlane((int)wm, d) >> bit) & 1u;
+            const uint32_t hbit = ((uint32_t)__builtin_amdgcn_readlane((int)wh, d) >> bit) & 1u;
+            const int oi = swap_roles ? cj : ri, oj = swap_roles ? ri : cj;   // the cell in the reference's coordinates
+            if (mbit) {                                    // MATCH: (i-1, j-1)
+                sink.put(1, oi, oj); --ri; --cj; ++d;
+            } else {
+                sink.put(hbit ? 2 : 3, oi, oj);            // INSERT : DELETE
+                if ((hbit != 0) != swap_roles) { --cj; ++d; }   // the array's column moves
+                else --ri;                                      // the array's row moves (same step, next bit down)
+            }
+        } while (ri > row_lo && cj > 0 && d <= dmax);
+    }
+}
+
 // One pair with its path.  full_band = false sweeps the narrow first-pass window and answers PBA_RC_UNCERTIFIED
 // (nothing reaches the sink) when its verdict cannot be certified; the host re-launches those pairs with
 // full_band = true, like the score-only kernels do.  min_matlen_a: the path is walked only when
 // matlen_a >= min_matlen_a (ref_seq::try_align's OVERLAP_MIN gate, ref_seq.h:265; 0 for plain scripts).
 // scratch: cap_words u32 of this wavefront's own.  Returns true when the path went to the sink.
-template <int NB, class Sink>
+// CK: the checkpoint form (scratch holds bv_ck_words, the walk re-runs chunks into `tile`: PBA_BV_TILE_WORDS(NB) uint2 of
+// LDS of this wavefront's own); else every step's words are streamed to scratch (bv_trace_words).
+template <int NB, bool CK, class Sink>
 __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
                                                    int maxn, int maxm, bool full_band, uint16_t *lds, int lds_cells,
                                                    uint32_t *scratch, uint64_t cap_words, int min_matlen_a, Sink &sink,
-                                                   AlnOut &o) {
+                                                   AlnOut &o, uint2 *tile = nullptr) {
     aln_params(la, lb, R, o);
     const int len_a = o.len_a, len_b = o.len_b, md = o.max_dst;
     if (maxn > 0 && (len_a >= maxn + maxm || md >= maxm)) return false;      // seq_aligner.h:104-107
@@ -142,8 +298,9 @@ __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
     const int w = full_band ? md : bv_pass1_w(md, NB), wl = full_band ? bv_full_wl(md) : bv_pass1_wl(md, NB);
     int best = 0, besti = 0, diag = 0;
-    if (bv_trace_words(NB, m, n, w) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return false; }   // host sizes both
-    const int fr = bitvec_pass<NB, true>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag, scratch, swap);
+    if ((CK ? bv_ck_words(NB, m, n, w) : bv_trace_words(NB, m, n, w)) > cap_words || wl + w > bv_max_span(NB)) { o.rc = -2; return false; }   // host sizes both
+    const int nr = min(n, m + w);
+    const int fr = bitvec_pass<NB, CK ? 2 : 1>(rowsF, nr, colsF, m, w, wl, R, best, besti, diag, scratch, swap);
     if (fr) {
         if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return false;
@@ -157,7 +314,8 @@ __device__ __forceinline__ bool align_bitvec_trace(const PackedFetch &fa, int la
     if (o.rc < 0 || o.matlen_a < min_matlen_a) return false;
     wave_mem_fence();                                   // the walk reads what other lanes stored
     int ri = besti, cj = m;                             // the goal cell in array coordinates: (row of the minimum, last column)
-    bv_trace_walk<NB>(scratch, ri, cj, swap, sink);
+    if constexpr (CK) bv_trace_walk_ck<NB>(rowsF, nr, colsF, m, w, wl, scratch, m + (nr + 32 * NB - 1) / (32 * NB) - 1, tile, ri, cj, swap, sink);
+    else bv_trace_walk<NB>(scratch, ri, cj, swap, sink);
     // border cells (init_cell): row 0 of the reference's matrix is INSERTs, column 0 DELETEs
     if (swap) {
         for (; ri > 0; --ri) sink.put(2, 0, ri);        // array rows are the reference's j

@@ -63,12 +63,19 @@ k_align_bytes_trace(const uint8_t *a, int a_dir, int la, const uint8_t *b, int b
 // ---- traceback on the bit-vector array (align_bvtrace.h): persistent wavefronts, each with its own scratch area
 // of wave_words u32 (cap_words of parent bits, then the goal-first ops of the pair in flight).
 // ids (nullable): the subset of pairs to process (second, full-band launch)
-template <int NB>
-__global__ void __launch_bounds__(PBA_WAVE * 4, NB <= 4 ? 4 : 2)
+// CK: the checkpoint form of the traced pass (align_bvtrace.h): scratch holds one checkpoint per 32 steps, the walk re-runs
+// chunks into this wavefront's LDS tile; else every step's parent words are streamed to scratch.
+#ifndef PBA_TR_OCC12
+#define PBA_TR_OCC12 6        // waves per SIMD of the checkpoint-form trace kernels at one or two blocks per lane (tuning hook;
+                              // 32 768 reads of BASELINE configs[1], same box: 4 -> 63.0 ms, 5 -> 60.0, 6 -> 50.7, 8 -> 52.3)
+#endif
+template <int NB, bool CK>
+__global__ void __launch_bounds__(PBA_WAVE * 4, NB <= 4 ? (CK && NB <= 2 ? PBA_TR_OCC12 : 4) : 2)
 k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg,
               pba_result *out, uint32_t *scratch, uint64_t wave_words, uint64_t cap_words, uint8_t *ops,
               const uint64_t *ops_off, int32_t *nedit, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
+    __shared__ uint2 s_tile[4][CK ? PBA_BV_TILE_WORDS(NB) : 1];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
     uint32_t *mine = scratch + ((uint64_t)blockIdx.x * 4 + wave) * wave_words;
@@ -83,8 +90,8 @@ k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *i
         int ne = 0;
         const uint64_t o0 = ops_off[q], o1 = ops_off[q + 1];
         OpSink sink{(uint8_t *)(mine + cap_words), 0, 0u};
-        if (align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
-                                   cfg.row_cap, mine, cap_words, 0, sink, o))
+        if (align_bitvec_trace<NB, CK>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
+                                       cfg.row_cap, mine, cap_words, 0, sink, o, s_tile[wave]))
             ne = sink.finish(ops + o0, o1 - o0);
         store_result(out + q, o);
         if ((threadIdx.x & (PBA_WAVE - 1)) == 0) nedit[q] = ne;
@@ -94,12 +101,13 @@ k_trace_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *i
 // The same sweep and walk, but the path goes straight into the vote boxes of an unlocked reference (consensus.h:
 // VoteSink) -- ref_seq::try_align's align + OVERLAP_MIN gate + elect (ref_seq.h:264-267) for a batch, no script in
 // memory.  a is the reference: pair.a_pos is the position the votes start at.
-template <int NB>
-__global__ void __launch_bounds__(PBA_WAVE * 4, NB <= 4 ? 4 : 2)
+template <int NB, bool CK>
+__global__ void __launch_bounds__(PBA_WAVE * 4, NB <= 4 ? (CK && NB <= 2 ? PBA_TR_OCC12 : 4) : 2)
 k_vote_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *ids, uint32_t n, AlignCfg cfg, int overlap_min,
              pba_result *out, uint32_t *scratch, uint64_t wave_words, uint64_t cap_words, ConsDev C, int beg, int pre, int post,
              uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
+    __shared__ uint2 s_tile[4][CK ? PBA_BV_TILE_WORDS(NB) : 1];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
     uint32_t *mine = scratch + ((uint64_t)blockIdx.x * 4 + wave) * wave_words;
@@ -113,8 +121,8 @@ k_vote_pairs(SeqSetDev A, SeqSetDev B, const pba_pair *pairs, const uint32_t *id
         const PackedFetch fb = fetch_of(B, pr.b_seq, pr.b_pos, (pr.flags & PBA_B_BACKWARD) ? -1 : 1);
         AlnOut o;
         VoteSink sink{C, beg + pr.a_pos, pre, post, fwd, fb, 0, 0, 0, 0u};
-        if (align_bitvec_trace<NB>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
-                                   cfg.row_cap, mine, cap_words, overlap_min, sink, o))
+        if (align_bitvec_trace<NB, CK>(fa, pr.a_len, fb, pr.b_len, cfg.R, cfg.maxn, cfg.maxm, cfg.full_band != 0, (uint16_t *)lds,
+                                       cfg.row_cap, mine, cap_words, overlap_min, sink, o, s_tile[wave]))
             sink.finish();
         store_result(out + q, o);
     }
@@ -352,12 +360,13 @@ int pba_align_text_matrix(pba_ctx *ctx, const char *a, int a_fwd, int la, const 
 }
 
 // scratch the traced bit-vector pass of one pair needs (u32 words): narrow first pass or reference band
-static uint64_t trace_words_of(int la, int lb, double R, int nb, bool full_band) {
+static uint64_t trace_words_of(int la, int lb, double R, int nb, bool full_band, bool ck) {
     const int md = max_dst_of(la, lb, R);
     const int len_a = lb >= la ? la : std::min(la, lb + md), len_b = lb >= la ? std::min(lb, la + md) : lb;
     const int m = std::min(len_a, len_b), n = std::max(len_a, len_b);
     if (m <= 10) return (((uint64_t)len_a + 1) * (2ull * md + 1) + 3) / 4;       // the row sweep's corner: byte codes
-    return bv_trace_words(nb, m, n, full_band ? md : bv_pass1_w(md, nb));
+    const int w = full_band ? md : bv_pass1_w(md, nb);
+    return ck ? bv_ck_words(nb, m, n, w) : bv_trace_words(nb, m, n, w);
 }
 
 
@@ -437,6 +446,10 @@ int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pa
         // launch: the pairs that came back uncertified, reference band.
         ctx->prof.nb_first = (uint32_t)pl.nb1; ctx->prof.n_first = (uint32_t)n;
         ctx->prof.nb_redo = 0; ctx->prof.n_redo = 0; ctx->prof.align_redo_ms = 0.f;
+        // checkpoints + recomputation (default) or every step's words streamed to HBM (PBA_TRACE_STREAM=1: the round-1 form,
+        // kept for comparison)
+        const char *e_stream = getenv("PBA_TRACE_STREAM");
+        const bool ck = !(e_stream && atoi(e_stream) != 0);
         std::vector<uint32_t> redo;
         for (int pass = 0; pass < 2; ++pass) {
             const int nb = pass ? pl.nb2 : pl.nb1;
@@ -444,7 +457,7 @@ int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pa
             uint64_t cap_words = 128;
             for (uint32_t k = 0; k < cnt; ++k) {
                 const pba_pair &p = pairs[pass ? redo[k] : k];
-                cap_words = std::max(cap_words, trace_words_of(p.a_len, p.b_len, R, nb, pass != 0));
+                cap_words = std::max(cap_words, trace_words_of(p.a_len, p.b_len, R, nb, pass != 0, ck));
             }
             cap_words = (cap_words + 63) & ~63ull;
             const uint64_t wave_words = cap_words + ((ops_max + 64 + 255) & ~255ull) / 4;
@@ -469,16 +482,18 @@ int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pa
             }
             HIPCHK(hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
             (void)hipEventRecord(ctx->ev[pass ? 4 : 2], ctx->stream);
-#define K_TRACE(NBV)                                                                                                  \
+#define K_TRACE2(NBV, CKV)                                                                                            \
     if (vote)                                                                                                         \
-        hipLaunchKernelGGL(k_vote_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
+        hipLaunchKernelGGL((k_vote_pairs<NBV, CKV>), dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
                            d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, overlap_min, d_out.as<pba_result>(),              \
                            d_scr, wave_words, cap_words, vdev, vbeg, vpre, vpost, ctx->d_queue);        \
     else                                                                                                              \
-        hipLaunchKernelGGL(k_trace_pairs<NBV>, dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
+        hipLaunchKernelGGL((k_trace_pairs<NBV, CKV>), dim3(grid), dim3(PBA_WAVE * 4), pl.lds * 4, ctx->stream, A->dev(), B->dev(), \
                            d_pairs.as<pba_pair>(), ids, cnt, pl.cfg, d_out.as<pba_result>(), d_scr,     \
                            wave_words, cap_words, d_ops.as<uint8_t>(), d_ooff.as<uint64_t>(), d_ne.as<int32_t>(),      \
                            ctx->d_queue)
+#define K_TRACE(NBV)                                                                                                  \
+    if (ck) { K_TRACE2(NBV, true); } else { K_TRACE2(NBV, false); }
             switch (nb) {
                 case 1: K_TRACE(1); break;
                 case 2: K_TRACE(2); break;
@@ -488,6 +503,7 @@ int trace_batch(pba_ctx *ctx, const pba_seqs *A, const pba_seqs *B, const pba_pa
                 default: K_TRACE(8); break;
             }
 #undef K_TRACE
+#undef K_TRACE2
             (void)hipEventRecord(ctx->ev[pass ? 5 : 3], ctx->stream);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_result) * n, hipMemcpyDeviceToHost, ctx->stream));

@@ -54,7 +54,13 @@ if nb:
 else:
     stream = (m + 1) * (2 * md + 1)
 cells_ref = float(np.mean((pairs["a_len"].astype(np.float64) + 1) * (2 * md + 1)))
+# the default form stores one checkpoint per 32 steps (Pv / Mv of every block and lane, the lane's window state, the two
+# hand-off masks) and re-runs the sweep chunk by chunk for the walk: (steps / 32 + 2) * (nb * 128 + 128) words per pair
+stream_form = os.environ.get("PBA_TRACE_STREAM", "0") not in ("", "0")
+ck_bytes = ((m + (-(-n_rows // (32 * nb)) if nb else 0) - 1) // 32 + 2) * (nb * 128 + 128) * 4 if nb else 0
 print(json.dumps({"workload": f"traceback of {hit.size} true {a.read_len}-base pairs @15% (R={a.R}), kernel={'auto' if not a.kernel else a.kernel}",
+                  "form": "stream: 2 parent bits per processed cell to HBM" if stream_form else "checkpoint every 32 steps + recomputation into LDS",
+                  "checkpoint_bytes_per_pair": int(ck_bytes),
                   "pairs": int(hit.size), "kernel_ms": round(ms, 2), "wall_s_with_d2h": round(best[1], 3),
                   "scripts_per_s": round(hit.size / (ms / 1e3), 1), "mean_nedit": float(nedit.mean()), "nb": nb,
                   "parent_bits_bytes_per_pair": int(stream), "hbm_write_GBps": round(hit.size * stream / (ms / 1e3) / 1e9, 1),
