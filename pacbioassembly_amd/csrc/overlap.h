@@ -304,7 +304,7 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
 // candidate array (k_piece_sort).  A piece that still does not fit (one query with tens of thousands of candidates on one
 // target: tandem repeats) is reported for the global bitonic pass.
 #define PBA_OVL_SUB 256
-struct OvlPiece { uint32_t off, n; };
+typedef SegRef OvlPiece;       // {off, n}: a piece of a target's slice
 static __global__ void __launch_bounds__(1024)
 k_ovl_split(const uint32_t *big, const uint32_t *cand_off, const uint64_t *cand, uint64_t *tmp, uint32_t sub_mul,
             OvlPiece *pieces, uint32_t *n_pieces, uint32_t *max_piece) {

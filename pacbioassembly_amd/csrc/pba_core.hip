@@ -591,18 +591,29 @@ static int index_levels(pba_ctx *ctx, pba_index *ix, uint64_t n_upper, const uin
     // the index keeps the buffer the last level wrote; the other one is the temporary
     if (cur == 1) { ix->d_ent = (uint64_t *)ent[1]; ix->ent_cap = ent_cap[1]; second = ent[0]; second_cap = ent_cap[0]; }   // (the first is the spare now)
     if (total) {
-        // LDS by need, not by capacity: a 2 048-entry partition takes 16 KB, so ten workgroups share a CU instead of one
-        uint32_t pow2 = 2;
-        while (pow2 < h_stat[0]) pow2 <<= 1;
-        for (uint64_t p0 = 0; p0 < P; p0 += 0x40000000ull)
-            hipLaunchKernelGGL(k_part_sort, dim3((uint32_t)std::min<uint64_t>(P - p0, 0x40000000ull)), dim3(pow2 >= 4096 ? 1024 : 256),
-                               sizeof(uint64_t) * pow2, ctx->stream, ix->d_ent, ix->d_part_off + p0);
-        if (h_stat[1]) {                                                           // low-complexity targets: partitions beyond the LDS sort
+        // every partition sorted by key, then insertion order: k_seg_sort (buckets by the key's gathered care bits, sorted in
+        // wavefront registers); what it leaves -- partitions beyond 16 384 entries or with a bucket beyond 256: low-complexity
+        // targets -- goes through the global bitonic pass
+        const uint32_t ov_cap = (uint32_t)std::min<uint64_t>(P, 4096);
+        uint32_t *const ov = tile_pre;                                             // (free again: 1 + ov_cap <= P + 8 slots)
+        HIPCHK(hipMemsetAsync(ov, 0, sizeof(uint32_t), ctx->stream));
+        launch_seg_sort(ctx, ix->d_ent, ix->d_ent, ix->d_part_off, nullptr, P, std::max(h_stat[0], h_stat[1] ? 0xFFFFFFFFu : 0u),
+                        seg_bkt_key(ix->mask), ov, ov_cap);
+        std::vector<uint32_t> h_ov(1 + ov_cap, 0);
+        HIPCHK(hipMemcpyAsync(h_ov.data(), ov, sizeof(uint32_t) * (1 + ov_cap), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        if (h_ov[0]) {
             std::vector<uint32_t> h_off(P + 1);
             HIPCHK(hipMemcpyAsync(h_off.data(), ix->d_part_off, sizeof(uint32_t) * (P + 1), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            for (uint64_t q = 0; q < P; ++q)
-                if (h_off[q + 1] - h_off[q] > PBA_IX_LDS_SORT_CAP) {
+            std::vector<uint32_t> todo;
+            if (h_ov[0] > ov_cap) { for (uint64_t q = 0; q < P; ++q) todo.push_back((uint32_t)q); }   // (list overflow: check them all)
+            else todo.assign(h_ov.begin() + 1, h_ov.begin() + 1 + h_ov[0]);
+            std::sort(todo.begin(), todo.end());
+            todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+            for (uint32_t q : todo)
+                if (h_off[q + 1] - h_off[q] > 1) {
                     int st = sort_partition_global(ctx, ix->d_ent + h_off[q], h_off[q + 1] - h_off[q]);
                     if (st != PBA_OK) return st;
                 }

@@ -201,6 +201,42 @@ static inline bool pair_ok(const pba_seqs *S, uint32_t seq, int pos, int len, bo
     return backward ? (pos < L && pos - (len - 1) >= 0) : ((long long)pos + len <= L);
 }
 
+// the five move masks of compress(x, mask) (Hacker's Delight 7-4): gathers the bits of x under `mask` into a number
+static inline void compress_masks(uint32_t mask, uint32_t mv[5]) {
+    uint32_t m = mask, mk = ~m << 1;
+    for (int i = 0; i < 5; ++i) {
+        uint32_t mp = mk ^ (mk << 1);
+        mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
+        const uint32_t mvi = mp & m;
+        mv[i] = mvi;
+        m = (m ^ mvi) | (mvi >> (1 << i));
+        mk &= ~mp;
+    }
+}
+// how segments are spread over buckets by k_seg_sort (seed_index.h)
+static inline SegBkt seg_bkt_range() { SegBkt b; memset(&b, 0, sizeof b); b.mode = 0; return b; }
+static inline SegBkt seg_bkt_key(uint32_t mask) {
+    SegBkt b; memset(&b, 0, sizeof b);
+    b.mode = 1; b.mask = mask; b.care = __builtin_popcount(mask);
+    compress_masks(mask, b.mv);
+    return b;
+}
+// n_seg segments of at most max_n entries each (larger ones, and those with a bucket beyond 256 entries, are listed in
+// oversize[1 ..] for the caller's global pass; oversize[0] must be zero on entry)
+static inline void launch_seg_sort(pba_ctx *ctx, const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const SegRef *segs,
+                                   uint64_t n_seg, uint32_t max_n, const SegBkt &bk, uint32_t *oversize, uint32_t oversize_cap) {
+    for (uint64_t s0 = 0; s0 < n_seg; s0 += 0x40000000ull) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>(n_seg - s0, 0x40000000ull);
+        // (oversize ids are relative to the launch: only one launch unless there are more than 2^30 segments)
+        if (max_n <= 256 * PBA_SS_EPT)
+            hipLaunchKernelGGL(k_seg_sort<256>, dim3(g), dim3(256), 0, ctx->stream, src, dst, seg_off ? seg_off + s0 : nullptr,
+                               segs ? segs + s0 : nullptr, bk, oversize, oversize_cap);
+        else
+            hipLaunchKernelGGL(k_seg_sort<1024>, dim3(g), dim3(1024), 0, ctx->stream, src, dst, seg_off ? seg_off + s0 : nullptr,
+                               segs ? segs + s0 : nullptr, bk, oversize, oversize_cap);
+    }
+}
+
 // ---- internal entry points that cross translation units
 extern "C" {
 // sort one oversize partition / candidate piece in global memory (pba_core.hip)

@@ -240,11 +240,17 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     // 3. sort every target's slice = the reference's try order inside every (target, query): in LDS, in place; the big
     //    ones piece by piece through a second buffer
     if (total) {
-        uint32_t pow2 = 2;
-        while (pow2 < biggest_small) pow2 <<= 1;
-        // (a big slice takes most of a CU's LDS, so its workgroup is the only one there: 1 024 threads keep the CU busy)
-        hipLaunchKernelGGL(k_part_sort, dim3(nt), dim3(pow2 >= 4096 ? 1024 : 256), sizeof(uint64_t) * pow2, ctx->stream,
-                           d_cand.as<uint64_t>(), d_off.as<uint32_t>());
+        // k_seg_sort (seed_index.h): buckets by query range, every bucket sorted in wavefront registers.  What it reports
+        // back (a slice with one bucket beyond 256 entries: one query with hundreds of candidates on the target) goes
+        // through the global bitonic pass.
+        const uint32_t ov_cap = 4096;
+        DevBuf d_ov;
+        HIPCHK(hipMalloc(&d_ov.p, sizeof(uint32_t) * (1 + ov_cap) * 2));
+        uint32_t *const ov_small = d_ov.as<uint32_t>(), *const ov_piece = ov_small + 1 + ov_cap;
+        HIPCHK(hipMemsetAsync(d_ov.p, 0, sizeof(uint32_t) * (1 + ov_cap) * 2, ctx->stream));
+        launch_seg_sort(ctx, d_cand.as<uint64_t>(), d_cand.as<uint64_t>(), d_off.as<uint32_t>(), nullptr, nt,
+                        big.empty() ? biggest_small : 0xFFFFFFFFu, seg_bkt_range(), ov_small, ov_cap);
+        std::vector<SegRef> h_pieces;
         if (!big.empty()) {
             st.n_big_targets = (uint32_t)big.size();
             DevBuf d_big, d_pieces, d_pc;
@@ -262,22 +268,36 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
             HIPCHK(hipMemcpyAsync(h_pc, d_pc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipGetLastError());
-            uint32_t p2 = 2;
-            while (p2 < h_pc[1]) p2 <<= 1;
-            hipLaunchKernelGGL(k_piece_sort, dim3(h_pc[0]), dim3(p2 >= 4096 ? 1024 : 256), sizeof(uint64_t) * p2, ctx->stream,
-                               d_tmp.as<uint64_t>(), d_cand.as<uint64_t>(), d_pieces.as<OvlPiece>());
-            std::vector<OvlPiece> h_pieces(h_pc[0]);
-            HIPCHK(hipMemcpyAsync(h_pieces.data(), d_pieces.p, sizeof(OvlPiece) * h_pc[0], hipMemcpyDeviceToHost, ctx->stream));
+            launch_seg_sort(ctx, d_tmp.as<uint64_t>(), d_cand.as<uint64_t>(), nullptr, d_pieces.as<SegRef>(), h_pc[0], 0xFFFFFFFFu,
+                            seg_bkt_range(), ov_piece, ov_cap);
+            h_pieces.resize(h_pc[0]);
+            HIPCHK(hipMemcpyAsync(h_pieces.data(), d_pieces.p, sizeof(SegRef) * h_pc[0], hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             HIPCHK(hipGetLastError());
-            for (const OvlPiece &pc : h_pieces)                   // e.g. one query with > 16 384 candidates on a target
-                if (pc.n > PBA_IX_LDS_SORT_CAP) {
-                    rc = sort_partition_global(ctx, d_tmp.as<uint64_t>() + pc.off, pc.n);
-                    if (rc != PBA_OK) return rc;
-                    HIPCHK(hipMemcpyAsync(d_cand.as<uint64_t>() + pc.off, d_tmp.as<uint64_t>() + pc.off, sizeof(uint64_t) * pc.n,
-                                          hipMemcpyDeviceToDevice, ctx->stream));
-                }
         }
+        std::vector<uint32_t> h_ov((1 + ov_cap) * 2, 0);
+        HIPCHK(hipMemcpyAsync(h_ov.data(), d_ov.p, sizeof(uint32_t) * (1 + ov_cap) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        // (a full list means "check everything")
+        auto listed = [&](const uint32_t *ov, uint64_t n_seg) {
+            std::vector<uint32_t> v;
+            if (ov[0] > ov_cap) { v.resize(n_seg); for (uint64_t i = 0; i < n_seg; ++i) v[i] = (uint32_t)i; }
+            else v.assign(ov + 1, ov + 1 + ov[0]);
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            return v;
+        };
+        for (uint32_t i : listed(h_ov.data(), nt))                    // small slices with an overfull bucket (the big ones are cut into pieces)
+            if (h_slice[i] > 1 && h_slice[i] <= PBA_IX_LDS_SORT_CAP) {
+                rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], h_slice[i]);
+                if (rc != PBA_OK) return rc;
+            }
+        for (uint32_t i : listed(h_ov.data() + 1 + ov_cap, h_pieces.size()))   // pieces beyond one sort, or with an overfull bucket
+            if (i < h_pieces.size() && h_pieces[i].n > 1) {
+                rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_pieces[i].off, h_pieces[i].n);
+                if (rc != PBA_OK) return rc;
+            }
     }
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -389,6 +389,176 @@ k_scan_add(uint32_t *a, uint64_t n, const uint32_t *tile_pre) {
     for (int k = 0; k < 8; ++k) if (base + k < n) a[base + k] += c;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Segment sort: the entries of a segment (a hash partition of the index, a target's candidate slice or a piece of it)
+// are spread over buckets by an ORDER-PRESERVING map of their value -- the buckets in order are the segment in order --
+// and every bucket (20-40 entries) is sorted in the registers of one wavefront: a bitonic network over 64 lanes, 21
+// compare-exchange stages on lane shuffles, no LDS traffic, no workgroup barrier.  The LDS bitonic sort it replaces moved
+// every entry through LDS ~100 times (27 MB of LDS traffic for a 16 384-entry piece: 2.8 s of the 9.9 s of a
+// million-read all-vs-all, two thirds of a 500 Mb index build); here an entry is loaded once into a register, counted,
+// written to its bucket, and sorted there.
+//   mode 0: bucket = the top bits of (entry - smallest entry): candidate slices (query ids spread evenly over their
+//           range); all-ones entries (empty slots) go to a bucket of their own behind the others, unsorted
+//   mode 1: bucket = the top bits of the key's care bits gathered into a number (monotone in the key, and uniform: a hash
+//           partition holds keys from all over the key space) -- index partitions
+// Buckets of up to 256 entries are sorted (four registers per lane); a segment with a larger one (one query with
+// thousands of candidates on a target: tandem repeats; a low-complexity partition) is reported for the caller's global
+// bitonic pass, as are segments beyond PBA_SS_EPT entries per thread.
+#define PBA_SS_EPT 16
+#define PBA_SS_MAXBKT 1024
+#ifndef PBA_SS_AVG
+#define PBA_SS_AVG 40          // entries per bucket aimed at (upper end; tuning hook)
+#endif
+struct SegBkt {
+    int mode;
+    uint32_t mask, mv[5];     // mode 1: compress(key, mask) (Hacker's Delight 7-4)
+    int care;
+};
+struct SegRef { uint32_t off, n; };
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t x, int j) {
+    return (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)x, j, PBA_WAVE) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), j, PBA_WAVE) << 32;
+}
+__device__ __forceinline__ void wave_sort64(uint64_t &x, int lane) {          // 64 entries, one per lane, ascending by lane
+#pragma unroll
+    for (int k = 2; k <= PBA_WAVE; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint64_t y = shfl_xor64(x, j);
+            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+            x = keep_min ? (x < y ? x : y) : (x > y ? x : y);
+        }
+    }
+}
+__device__ __forceinline__ void wave_sort256(uint64_t (&x)[4], int lane) {   // entry r * 64 + lane in x[r]
+#pragma unroll
+    for (int k = 2; k <= 4 * PBA_WAVE; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= PBA_WAVE) {
+                const int rj = j / PBA_WAVE;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r & rj) continue;
+                    const bool up = ((r * PBA_WAVE) & k) == 0;
+                    const uint64_t a = x[r], b = x[r | rj];
+                    if ((a > b) == up) { x[r] = b; x[r | rj] = a; }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t y = shfl_xor64(x[r], j);
+                    const bool keep_min = ((lane & j) == 0) == (((r * PBA_WAVE + lane) & k) == 0);
+                    x[r] = keep_min ? (x[r] < y ? x[r] : y) : (x[r] > y ? x[r] : y);
+                }
+            }
+        }
+    }
+}
+// segs: SegRef per segment, or (segs == nullptr) seg_off[i] .. seg_off[i + 1].  src == dst is allowed (every entry is in a
+// register before the first store).  oversize[0] counts, oversize[1 + k] names the segments left to the caller.
+template <int T>
+static __global__ void __launch_bounds__(T)
+k_seg_sort(const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const SegRef *segs, SegBkt bk, uint32_t *oversize,
+           uint32_t oversize_cap) {
+    __shared__ uint32_t hist[PBA_SS_MAXBKT + 2], cur[PBA_SS_MAXBKT + 2], wsum[T / PBA_WAVE];
+    __shared__ unsigned long long s_min, s_max;
+    const uint32_t lo = segs ? segs[blockIdx.x].off : seg_off[blockIdx.x];
+    const uint32_t n = segs ? segs[blockIdx.x].n : seg_off[blockIdx.x + 1] - lo;
+    if (n < 2) { if (n == 1 && src != dst && threadIdx.x == 0) dst[lo] = src[lo]; return; }
+    if (n > T * PBA_SS_EPT) {                                        // beyond this launch: the caller's fallback
+        if (src != dst) for (uint32_t i = threadIdx.x; i < n; i += T) dst[lo + i] = src[lo + i];
+        if (threadIdx.x == 0) { const uint32_t k = atomicAdd(&oversize[0], 1u); if (k < oversize_cap) oversize[1 + k] = blockIdx.x; }
+        return;
+    }
+    const int lane = threadIdx.x & (PBA_WAVE - 1), wave = threadIdx.x / PBA_WAVE;
+    // 20-40 entries per bucket: a bucket takes the 64 lanes of a wavefront whatever it holds, so fuller is cheaper, and
+    // at 40 on average one bucket in 5 000 outgrows the one-register sort (measured: 8-16 per bucket left the sort as slow
+    // as the LDS network it replaces)
+    uint32_t nbkt = 1;
+    while (nbkt < PBA_SS_MAXBKT && nbkt * PBA_SS_AVG < n) nbkt <<= 1;
+    const int lg = 31 - __builtin_clz(nbkt);
+    uint64_t e[PBA_SS_EPT];
+    unsigned long long mn = ~0ull, mx = 0ull;
+#pragma unroll
+    for (int k = 0; k < PBA_SS_EPT; ++k) {
+        const uint32_t i = (uint32_t)k * T + threadIdx.x;
+        e[k] = i < n ? src[lo + i] : ~0ull;
+        if (e[k] != ~0ull) { mn = e[k] < mn ? e[k] : mn; mx = e[k] > mx ? e[k] : mx; }
+    }
+    for (uint32_t b = threadIdx.x; b < nbkt + 2; b += T) hist[b] = 0;
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (in place: every load has returned before any store)
+    __syncthreads();
+    int shift = 0;
+    if (bk.mode == 0) {
+#pragma unroll
+        for (int d = 1; d < PBA_WAVE; d <<= 1) {
+            const unsigned long long a = shfl_xor64(mn, d), b = shfl_xor64(mx, d);
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        }
+        if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+        __syncthreads();
+        mn = s_min; mx = s_max;
+        const unsigned long long range = mx >= mn ? mx - mn : 0ull;
+        const int bits = range ? 64 - __builtin_clzll(range) : 0;
+        shift = bits > lg ? min(bits - lg, 63) : 0;
+    }
+    auto bucket = [&](uint64_t v) -> uint32_t {
+        if (v == ~0ull) return nbkt;                                 // empty slots: behind everything, never sorted
+        if (bk.mode == 0) return (uint32_t)((v - mn) >> shift);
+        uint32_t x = (uint32_t)(v >> 32) & bk.mask;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const uint32_t t = x & bk.mv[i]; x = (x ^ t) | (t >> (1 << i)); }
+        return lg == 0 ? 0u : (bk.care > lg ? x >> (bk.care - lg) : x);              // (lg == 0: one bucket; a shift by 32 is not a shift)
+    };
+#pragma unroll
+    for (int k = 0; k < PBA_SS_EPT; ++k)
+        if ((uint32_t)k * T + threadIdx.x < n) atomicAdd(&hist[bucket(e[k])], 1u);
+    __syncthreads();
+    // exclusive scan of hist[0 .. nbkt) (T >= nbkt: one bin per thread): cur[b] = first slot of bucket b; the empty slots'
+    // bucket starts behind the last real one
+    {
+        const uint32_t c0 = threadIdx.x < nbkt ? hist[threadIdx.x] : 0u;
+        uint32_t inc = c0;
+#pragma unroll
+        for (int d = 1; d < PBA_WAVE; d <<= 1) { const uint32_t t = __shfl_up(inc, d, PBA_WAVE); if (lane >= d) inc += t; }
+        if (lane == PBA_WAVE - 1) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; ++w) carry += wsum[w];
+        if (threadIdx.x < nbkt) cur[threadIdx.x] = carry + inc - c0;
+        if (threadIdx.x == nbkt - 1) cur[nbkt] = carry + inc;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PBA_SS_EPT; ++k)
+        if ((uint32_t)k * T + threadIdx.x < n) dst[lo + atomicAdd(&cur[bucket(e[k])], 1u)] = e[k];
+    __threadfence_block();
+    __syncthreads();                                                 // cur[b] is now the END of bucket b
+    bool too_big = false;
+    for (uint32_t b = wave; b < nbkt; b += T / PBA_WAVE) {
+        const uint32_t c = hist[b], first = cur[b] - c;
+        if (c < 2) continue;
+        uint64_t *p = dst + lo + first;
+        if (c <= PBA_WAVE) {
+            uint64_t x = (uint32_t)lane < c ? p[lane] : ~0ull;
+            wave_sort64(x, lane);
+            if ((uint32_t)lane < c) p[lane] = x;
+        } else if (c <= 4 * PBA_WAVE) {
+            uint64_t x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = (uint32_t)(r * PBA_WAVE + lane) < c ? p[r * PBA_WAVE + lane] : ~0ull;
+            wave_sort256(x, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if ((uint32_t)(r * PBA_WAVE + lane) < c) p[r * PBA_WAVE + lane] = x[r];
+        } else too_big = true;
+    }
+    if (__builtin_amdgcn_ballot_w64(too_big) && lane == 0) {
+        const uint32_t k = atomicAdd(&oversize[0], 1u);
+        if (k < oversize_cap) oversize[1 + k] = blockIdx.x;
+    }
+}
+
 // pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
 static __global__ void __launch_bounds__(1024) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
     extern __shared__ __align__(16) uint64_t s_ent[];
