@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--coverage", type=float, default=20.0, help="all-vs-all: genome = reads x read_len / coverage")
     ap.add_argument("--overlap-trials", type=int, default=32)
     ap.add_argument("--targets-per-call", type=int, default=25_000)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; gloo + PBA_BENCH_SHARE_GPU=1 rehearses the N > 1 paths with several ranks "
+                         "on ONE GPU (a 1-GPU box; RCCL itself needs one GPU per rank)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: every rank joins a gloo process group, the ranks are summed, rank 0 prints the census "
                          "(checks the launcher and the rendezvous on a box without GPUs)")
@@ -278,13 +281,18 @@ def run_rank(a):
 
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py rank {rank}: needs an MI355X, there is no CPU path to time (no GPU visible)")
+    if os.environ.get("PBA_BENCH_SHARE_GPU") == "1":                  # rehearsal: the ranks share the GPUs there are
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.exchange
     if use_dist:
         os.environ["NCCL_DEBUG"] = os.environ.get("PBA_NCCL_DEBUG", "WARN")   # no RCCL banner on stdout: ONE JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = Context(local_rank)
     nthreads = a.cpu_threads or max(1, host_cores() // (world if "LOCAL_WORLD_SIZE" in os.environ else 1))
 

@@ -13,7 +13,7 @@
 //                  candidate = query << 23 | (2j + backward) << 16 | ordinal
 //   (per-target sort of the candidates in LDS; 64-bit order = query, then j, forward before backward, then the
 //    seedmap's list order -- exactly the order spaced_seed tries them in; big targets are cut into pieces of
-//    consecutive queries first: k_ovl_split, k_piece_sort)
+//    consecutive queries first: k_ovl_split, then k_seg_sort piece by piece)
 //   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query;
 //                  (target, query) runs whose narrow-window verdict is not certified are parked and resumed by a
 //                  second launch at the reference band
@@ -301,7 +301,7 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
 // consecutive queries first: PBA_OVL_SUB fine buckets (bucket = umulhi(q, 2^32 * SUB / n_reads), monotone in q; the
 // all-ones slots go last), neighbours merged greedily into pieces that fit, the slice scattered piece by piece into a
 // second buffer -- the pieces in order are the list in query order, and each is then sorted on its own back into the
-// candidate array (k_piece_sort).  A piece that still does not fit (one query with tens of thousands of candidates on one
+// candidate array (k_seg_sort).  A piece that still does not fit (one query with tens of thousands of candidates on one
 // target: tandem repeats) is reported for the global bitonic pass.
 #define PBA_OVL_SUB 256
 typedef SegRef OvlPiece;       // {off, n}: a piece of a target's slice
@@ -344,32 +344,6 @@ k_ovl_split(const uint32_t *big, const uint32_t *cand_off, const uint64_t *cand,
         tmp[lo + atomicAdd(&pcur[piece_of[bucket(cd)]], 1u)] = cd;
     }
 }
-// one workgroup sorts one piece in LDS, from src into dst (bitonic network on 64-bit entries); oversize pieces are left
-// to the host's global pass
-static __global__ void __launch_bounds__(1024)
-k_piece_sort(const uint64_t *src, uint64_t *dst, const OvlPiece *pieces) {
-    extern __shared__ __align__(16) uint64_t s_ent[];
-    const uint32_t lo = pieces[blockIdx.x].off, n = pieces[blockIdx.x].n;
-    if (n > PBA_IX_LDS_SORT_CAP) return;
-    uint32_t N = 2;
-    while (N < n) N <<= 1;
-    for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s_ent[i] = i < n ? src[lo + i] : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t l = i | j;
-                const uint64_t x = s_ent[i], y = s_ent[l];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) { s_ent[i] = y; s_ent[l] = x; }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[lo + i] = s_ent[i];
-}
-
 // work item i of a call = (target, first candidate of its group of 64): item_pre[t] = items of the targets before t
 static __global__ void __launch_bounds__(256)
 k_ovl_items(const uint32_t *item_pre, const uint32_t *cand_off, uint32_t n_targets, uint32_t n_items, uint2 *items) {

@@ -62,13 +62,6 @@ k_make_planes(const uint8_t *packed, const uint64_t *off, const uint32_t *len, c
 }
 
 
-static void tu_attrs() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    PBA_BIG_LDS(k_part_sort);
-}
-
 extern "C" {
 
 int pba_ctx_create(int device_id, pba_ctx **out) {
@@ -513,7 +506,6 @@ static int index_levels(pba_ctx *ctx, pba_index *ix, uint64_t n_upper, const uin
     ix->logP = index_logp(n_upper);
     const int logP = ix->logP, n_levels = std::max(1, (logP + PBA_IX_LVL_BITS - 1) / PBA_IX_LVL_BITS);
     const uint64_t P = 1ull << logP;
-    tu_attrs();
     // device arrays: two entry buffers (the levels ping-pong; the last one written becomes the index's), the offsets of
     // every level (2^depth + 1 each), cursors, tile tables, scan scratch
     void *ent[2] = {nullptr, nullptr};

@@ -8,7 +8,6 @@ static void tu_attrs() {
     static bool done = false;
     if (done) return;
     done = true;
-    PBA_BIG_LDS(k_part_sort);
     PBA_BIG_LDS(k_ovl_walk<0>);
 }
 

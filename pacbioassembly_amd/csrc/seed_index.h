@@ -25,7 +25,7 @@
 #define PBA_IX_MAX_LOGP 24                 // partitions of ~2 048 entries for up to 2^32 entries (minus the average)
 #define PBA_IX_LVL_BITS 8                  // hash bits one partition level resolves (256 bins: two u32 LDS tables = 2 KB)
 #define PBA_IX_PART_AVG 2048               // entries per partition the builder aims at (1 024 .. 2 048)
-#define PBA_IX_LDS_SORT_CAP 16384          // entries one workgroup sorts in LDS (128 KB)
+#define PBA_IX_LDS_SORT_CAP 16384          // entries of the largest segment one k_seg_sort workgroup takes (1 024 threads x 16)
 #define PBA_IX_TILE_THREADS 256
 #define PBA_IX_TILE_ITERS 4
 #define PBA_IX_TILE_POS (PBA_IX_TILE_THREADS * 16 * PBA_IX_TILE_ITERS)   // positions per workgroup
@@ -83,38 +83,6 @@ __device__ __forceinline__ void ix_find(const IndexDev &ix, uint32_t key, uint32
     const uint32_t lo = ix.part_off[p], hi = ix.part_off[p + 1];
     beg = ix_lower_bound(ix.ent, lo, hi, (uint64_t)key << 32);
     cnt = ix_run_end(ix.ent, beg, hi, key) - beg;
-}
-
-// Direct-address directory over an index (the all-vs-all scan looks a key up for every position of every read: the
-// partition's binary search is ~15 dependent loads, this is one).  A key under a mask of w care bits is one of 2^w
-// values: dir[compress(key)] = first entry of the key's run, or PBA_DIR_EMPTY.  compress() gathers the care bits
-// (Hacker's Delight 7-4, the five move masks precomputed on the host for the mask).
-#define PBA_DIR_EMPTY 0xFFFFFFFFu
-#define PBA_DIR_MAX_BITS 26
-struct KeyDir {
-    const uint32_t *dir;     // nullptr: no directory (mask too heavy), fall back to ix_find
-    uint32_t mask, mv[5];
-    uint32_t n_entries;
-};
-__device__ __forceinline__ uint32_t dir_compress(const KeyDir &d, uint32_t x) {
-    x &= d.mask;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const uint32_t t = x & d.mv[i];
-        x = (x ^ t) | (t >> (1 << i));
-    }
-    return x;
-}
-__device__ __forceinline__ void dir_find(const KeyDir &d, const uint64_t *ent, uint32_t key, uint32_t &beg, uint32_t &cnt) {
-    beg = d.dir[dir_compress(d, key)];
-    cnt = beg == PBA_DIR_EMPTY ? 0u : ix_run_end(ent, beg, d.n_entries, key) - beg;
-}
-static __global__ void __launch_bounds__(256)
-k_dir_build(const uint64_t *ent, uint32_t n, KeyDir d, uint32_t *dir) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t key = (uint32_t)(ent[i] >> 32);
-    if (i == 0 || (uint32_t)(ent[i - 1] >> 32) != key) dir[dir_compress(d, key)] = i;   // equal keys are contiguous (same partition, sorted)
 }
 
 // One scan segment: positions [lo, hi) of a sequence, visited ascending (ord = ord0 + pos - lo)
@@ -559,31 +527,7 @@ k_seg_sort(const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const Se
     }
 }
 
-// pass 3: one workgroup sorts one partition in LDS (bitonic network on 64-bit entries)
-static __global__ void __launch_bounds__(1024) k_part_sort(uint64_t *ent, const uint32_t *part_off) {
-    extern __shared__ __align__(16) uint64_t s_ent[];
-    const uint32_t lo = part_off[blockIdx.x], n = part_off[blockIdx.x + 1] - lo;
-    if (n < 2 || n > PBA_IX_LDS_SORT_CAP) return;     // oversize partitions take the global path
-    uint32_t N = 2;
-    while (N < n) N <<= 1;
-    for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) s_ent[i] = i < n ? ent[lo + i] : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // low element of the pair
-                const uint32_t l = i | j;
-                const uint64_t x = s_ent[i], y = s_ent[l];
-                const bool up = (i & k) == 0;
-                if ((x > y) == up) { s_ent[i] = y; s_ent[l] = x; }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) ent[lo + i] = s_ent[i];
-}
-
-// global-memory bitonic step for partitions too large for LDS (low-complexity targets)
+// global-memory bitonic step for the segments k_seg_sort leaves to the caller (low-complexity targets, tandem repeats)
 static __global__ void k_bitonic_step(uint64_t *buf, uint32_t N, uint32_t k, uint32_t j) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (N >> 1)) return;

@@ -1281,3 +1281,35 @@ def test_locate_random_configs_vs_oracle():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("same=True") == 4
+
+
+def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
+    """The N > 1 paths of bench.py on the GPU box there is: two ranks (started by bench.py's own launcher) share the one GPU
+    and exchange over gloo instead of RCCL (which needs a GPU per rank) -- seed-index exchange and locate in weak scaling,
+    then the all-vs-all leg with its packed-read all-gather, probe exchange and target shards.  The strong-scaling counts
+    (candidates, pairs, overlaps) equal the one-rank run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["PBA_BENCH_SHARE_GPU"] = "1"
+    common = ["--reads", "3000", "--overlap-reads", "12000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0"]
+
+    def run(*args):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, *common], env=env, capture_output=True, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    two = run("--gpus", "2", "--backend", "gloo")
+    one = run("--gpus", "1")
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["pairs_per_step"] > one["pairs_per_step"] > 10000
+    a, b = two["overlap_strong"], one["overlap_strong"]
+    assert a["world_size"] == 2 and a["scaling"] == "strong" and len(a["per_rank"]["walk_s"]) == 2
+    for k in ("pairs_per_step", "overlaps_per_step", "candidates_per_step"):
+        assert a[k] == b[k] > 1000, k
+    ovl = run("--gpus", "2", "--backend", "gloo", "--mode", "overlap")
+    assert ovl["scaling"] == "strong" and ovl["overlap"]["pairs_per_step"] == b["pairs_per_step"]
