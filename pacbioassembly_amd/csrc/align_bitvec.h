@@ -49,6 +49,7 @@
 #include "dev_common.h"
 
 #define PBA_BV_MAX_NB 8
+#define PBA_BV_FIN_WORDS(nb) ((2 * (nb) + 1) * 64)     // u32 of LDS per wavefront for the last column's deltas (bitvec_pass: fin)
 #define PBA_BV_BAND_NUM 9      // first-pass half width = max(max_dst/2, 9/16 * max_dst) + 1
 #define PBA_BV_BAND_DEN 16
 
@@ -163,8 +164,8 @@ __device__ __forceinline__ void bv_ckpt_store(uint32_t *tr, int tb, int lane, co
 
 template <int NB, int TRACE = 0>
 __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
-                                           double R, int &best_out, int &besti_out, int &diag_out, uint32_t *tr = nullptr,
-                                           bool swap_roles = false) {
+                                           double R, int &best_out, int &besti_out, int &diag_out, uint32_t *fin,
+                                           uint32_t *tr = nullptr, bool swap_roles = false) {
     // rowsF / nr: the longer sequence and how many of its rows are swept (m <= nr <= m + wleft); colsF / m: the shorter
     // one.  Row i sees the columns [i - wleft, i + w] (wleft: the wide side, towards the free end; w: the narrow one).
     constexpr int RB = 32 * NB;                 // rows per superblock
@@ -181,9 +182,11 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     uint32_t Pv[NB], Mv[NB], Plo[NB], Phi[NB], acc[NB];
     int s_cur = lane;
     int t_evt;         // next step at which this lane's window opens or (after that) has just closed
-    int t_close1 = 0;  // first step after the window
-    int t_hin_end;     // last step at which the lane above still delivers hout for this lane's column
-    int t_diag0;       // step at which this lane's first row is on the diagonal
+    // functions of the superblock the lane holds, recomputed where an event needs them (three registers fewer to carry
+    // through the step loop: at 64 registers per lane they were what the event handler spilled to scratch memory):
+    auto t_close1 = [&]() { return s_cur < S ? min(m, s_cur * RB + RB + w) + s_cur + 1 : INT_MAX; };          // first step after the window
+    auto t_hin_end = [&]() { return (s_cur < S && s_cur > 0) ? min(m, s_cur * RB + w) + s_cur : INT_MIN; };   // last step at which the lane above still delivers hout for this lane's column
+    auto t_diag0 = [&]() { return (s_cur < S && s_cur * RB < m) ? s_cur * RB + 1 + s_cur : INT_MAX - RB; };   // step at which this lane's first row is on the diagonal
     int t_dstart;      // = t_diag0 until the diagonal has entered this lane's rows
     int t_seg;         // step at which the current 32-row diagonal segment of this lane is complete
     uint32_t opened = 0;   // 0 / 1 in a VGPR (a bool would live in an SGPR pair and be re-merged with exec every step)
@@ -194,16 +197,15 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
         if (s_cur < S) {
             const int lo = max(1, base_row + 1 - wleft), hi = min(m, base_row + RB + w);
             t_evt = lo + s_cur;
-            t_close1 = hi + s_cur + 1;
-            t_hin_end = s_cur > 0 ? min(m, base_row + w) + s_cur : INT_MIN;
+            (void)hi;
             if (base_row < m) {                 // the diagonal (rows 1..m) crosses this superblock
-                t_diag0 = t_dstart = base_row + 1 + s_cur;
-                t_seg = min(t_diag0 + 31, m + s_cur);
-            } else { t_diag0 = INT_MAX - RB; t_dstart = INT_MAX; t_seg = INT_MAX - 1; }
+                t_dstart = base_row + 1 + s_cur;
+                t_seg = min(t_dstart + 31, m + s_cur);
+            } else { t_dstart = INT_MAX; t_seg = INT_MAX - 1; }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) load_planes32(rowsF, base_row + 32 * nb, Plo[nb], Phi[nb]);
         } else {                                // nothing left for this lane
-            t_evt = INT_MAX; t_close1 = INT_MAX; t_hin_end = INT_MIN; t_diag0 = INT_MAX - RB; t_dstart = INT_MAX;
+            t_evt = INT_MAX; t_dstart = INT_MAX;
             t_seg = INT_MAX - 1;
         }
     };
@@ -215,16 +217,16 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     int score = 0, best = INT_MAX, fail_row = 0;
     // the vertical deltas of the LAST column as this lane's last superblock at or below row m left them (a lane keeps
     // stepping on garbage after its window has closed, so they are put aside at the close); fin_s: that superblock, or -1
-    uint32_t fin_pv[NB], fin_mv[NB];
-    int fin_s = -1;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { fin_pv[nb] = 0u; fin_mv[nb] = 0u; }
+    // They live in LDS (fin: PBA_BV_FIN_WORDS(NB) u32 of this wavefront's own: [2*nb][lane] Pv, [2*nb+1][lane] Mv, [2*NB][lane]
+    // the superblock): written once per superblock that reaches the last column, read once at the end -- as registers
+    // they were live through the whole step loop, and at 64 registers per lane the compiler spilled them to scratch memory.
+    fin[2 * NB * PBA_WAVE + lane] = 0xFFFFFFFFu;
     uint32_t dmw = 0;                            // one-hot: bit of the diagonal cell in its block's word (0: not in this lane)
     uint64_t hp_last = ~0ull, hn_last = 0ull;    // lane masks: delta +1 / -1 leaving each lane's last block in the previous step
     // lanes whose first block still receives the lane above's hout (the others see "+1 per column")
-    uint64_t valid = __builtin_amdgcn_ballot_w64(1 <= t_hin_end);
+    uint64_t valid = __builtin_amdgcn_ballot_w64(1 <= t_hin_end());
     // the one rare-event compare of the step loop
-    int t_next = min(min(t_evt, t_seg + 1), min(t_dstart, 1 <= t_hin_end ? t_hin_end + 1 : INT_MAX));
+    int t_next = min(min(t_evt, t_seg + 1), min(t_dstart, 1 <= t_hin_end() ? t_hin_end() + 1 : INT_MAX));
 
     // text planes for the 32 steps starting at the wave-uniform step tb (element of step t is t - s_cur - 1)
     auto load_text = [&](int tb) { load_planes32(colsF, tb - s_cur - 1, wl, wh); };
@@ -233,7 +235,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     // seq_aligner.h:185 and carry the diagonal score on.
     // `above`: the score register of the lane above, fetched by the caller with all lanes enabled
     auto segment_done = [&](int t, int above) {
-        const int rr = t - 1 - t_diag0, i = t - 1 - s_cur, cnt = (rr & 31) + 1, i0 = i - cnt, q = rr >> 5;
+        const int rr = t - 1 - t_diag0(), i = t - 1 - s_cur, cnt = (rr & 31) + 1, i0 = i - cnt, q = rr >> 5;
         if (q == 0) score = s_cur == 0 ? 0 : above;      // D(i0,i0): the lane above finished its rows >= 2 steps ago
         uint32_t dw = 0;
 #pragma unroll
@@ -268,24 +270,25 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
                the ramp one lane opens per step, and false candidates are all ramp) */                              \
             if (opened) {                                                             \
                 if (s_cur >= s_m) {          /* its window ended with the last column: keep that column */ \
-                    fin_s = s_cur;                                                    \
-                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { fin_pv[nb] = Pv[nb]; fin_mv[nb] = Mv[nb]; } \
+                    fin[2 * NB * PBA_WAVE + lane] = (uint32_t)s_cur;                  \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { fin[2 * nb * PBA_WAVE + lane] = Pv[nb]; fin[(2 * nb + 1) * PBA_WAVE + lane] = Mv[nb]; } \
                 }                                                                     \
                 s_cur += PBA_WAVE; open_superblock(); load_text(t - ((t - 1) & 31));  \
             }                                                                         \
             if (t == t_evt) {                                                         \
                 _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) { Pv[nb] = ~0u; Mv[nb] = 0u; } \
                 opened = 1;                                                           \
-                t_evt = t_close1;                                                     \
+                t_evt = t_close1();                                                   \
             }                                                                         \
         }                                                                             \
         if (t == t_dstart) {                                                          \
             dmw = 1u; t_dstart = INT_MAX;                                             \
             _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] = 0;            \
         }                                                                             \
-        t_next = min(min(t_evt, t_seg + 1), min(t_dstart, t <= t_hin_end ? t_hin_end + 1 : INT_MAX)); \
+        { const int he = t_hin_end();                                                 \
+          t_next = min(min(t_evt, t_seg + 1), min(t_dstart, t <= he ? he + 1 : INT_MAX)); } \
       }                                                                               \
-      valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end);   /* changes only at events: kept as a scalar mask */ \
+      valid = __builtin_amdgcn_ballot_w64(t <= t_hin_end());   /* changes only at events: kept as a scalar mask */ \
       if constexpr (TRACE == 1) st_on = ((__builtin_amdgcn_ballot_w64(opened != 0) >> (lane & 48)) & 0xFFFFull) != 0; \
       ON_EVENT;                                                                       \
     }
@@ -373,7 +376,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
         return __builtin_amdgcn_readfirstlane(fr);
     }
     t_seg = INT_MAX - 1; t_dstart = INT_MAX;
-    t_next = min(t_evt, t <= t_hin_end ? t_hin_end + 1 : INT_MAX);
+    t_next = min(t_evt, t <= t_hin_end() ? t_hin_end() + 1 : INT_MAX);
 
     // ------------------------------------------------------------------ phase 2: the superblocks below row m take the last column
     for (int tb = t1 + 1; tb <= t_end;) {
@@ -411,19 +414,21 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     // upward from the diagonal, and keeps the first strict minimum).  A lane whose window is still open holds the
     // column in Pv / Mv, the others put it aside when their window closed.
     if (opened && s_cur >= s_m && s_cur < S) {
-        fin_s = s_cur;
+        fin[2 * NB * PBA_WAVE + lane] = (uint32_t)s_cur;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { fin_pv[nb] = Pv[nb]; fin_mv[nb] = Mv[nb]; }
+        for (int nb = 0; nb < NB; ++nb) { fin[2 * nb * PBA_WAVE + lane] = Pv[nb]; fin[(2 * nb + 1) * PBA_WAVE + lane] = Mv[nb]; }
     }
+    const int fin_s = (int)fin[2 * NB * PBA_WAVE + lane];      // (a lane reads what it wrote itself: no barrier)
     int b_tot[NB], b_min[NB], b_pos[NB];          // per block of this lane's last superblock: sum, lowest prefix sum, its bit
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int row0 = fin_s * RB + nb * 32;    // bit r is row row0 + r + 1
+        const uint32_t fpv = fin_s >= 0 ? fin[2 * nb * PBA_WAVE + lane] : 0u, fmv = fin_s >= 0 ? fin[(2 * nb + 1) * PBA_WAVE + lane] : 0u;
         int v = 0, pm = INT_MAX, pp = 0;
         for (int r = 0; r < 32; ++r) {
             const int row = row0 + r + 1;
             if (fin_s >= 0 && row > m && row <= nr) {
-                v += (int)((fin_pv[nb] >> r) & 1u) - (int)((fin_mv[nb] >> r) & 1u);
+                v += (int)((fpv >> r) & 1u) - (int)((fmv >> r) & 1u);
                 if (v < pm) { pm = v; pp = r; }
             }
         }
@@ -492,7 +497,7 @@ __device__ __forceinline__ bool bv_goal_certified(int best, int wl, int w, int m
 // need is valid).  full_band = false runs the narrow first pass and reports PBA_RC_UNCERTIFIED when the
 // goal row cannot be certified; the host then re-launches those pairs with full_band = true.
 // There is deliberately no device function call in here: everything inlines into the kernel.
-// lds: >= 256 bytes (only the m <= 10 corner uses it, through the row sweep)
+// lds: PBA_BV_FIN_WORDS(NB) u32 of this wavefront's own (>= 256 bytes: the m <= 10 corner runs the row sweep in it)
 // need_diag: the caller reports D(m,m) (locator.cpp:86): a narrow pass whose window cannot vouch for that cell too
 // answers PBA_RC_UNCERTIFIED; without it o.diag is -1 in that case.
 template <int NB>
@@ -513,7 +518,7 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
     if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
     int best = 0, besti = 0, diag = 0;
-    const int fr = bitvec_pass<NB>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag);
+    const int fr = bitvec_pass<NB>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag, (uint32_t *)lds);
     if (fr) {
         if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return;

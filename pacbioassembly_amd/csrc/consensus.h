@@ -109,6 +109,19 @@ struct VoteSink {
         ++k;
         if ((k & (PBA_WAVE - 1)) == 0) apply();
     }
+    // n MATCH votes down a diagonal from cell (i, j): vote k + r is the MATCH at (i - r, j - r)
+    __device__ __forceinline__ void put_run(int n, int i, int j) {
+        const int lane = threadIdx.x & (PBA_WAVE - 1);
+        while (n > 0) {
+            const int at = k & (PBA_WAVE - 1), take = min(n, PBA_WAVE - at);
+            if (lane >= at && lane < at + take) {
+                const int r = lane - at;
+                p_op = 1u; p_at = fwd ? it0 + (i - r - 1) : it0 - (i - r - 1); p_j = j - r;
+            }
+            k += take; n -= take; i -= take; j -= take;
+            if ((k & (PBA_WAVE - 1)) == 0) apply();
+        }
+    }
     __device__ __forceinline__ void finish() { apply(); }
 };
 

@@ -167,7 +167,8 @@ static inline int make_plan(pba_ctx *ctx, double R, int maxn, int maxm, int kern
     if (kernel == PBA_KERNEL_BITVEC && !bv) PBA_FAIL(PBA_E_TOOLONG, "band too wide for the bit-vector kernel");
     // the bit-vector kernel needs LDS only for its m <= 10 corner (a 23-cell row at most); the row sweep
     // needs the whole band row
-    const long long W = bv ? 127 : 2ll * max_dst_max + 1;
+    const int nb_hi = bv ? bv_nb_for_span(bv_full_wl(max_dst_max) + max_dst_max) : 0;     // the most blocks per lane a launch of this plan uses
+    const long long W = bv ? (long long)PBA_BV_FIN_WORDS(nb_hi) * 2 : 2ll * max_dst_max + 1;   // (u16 cells: the fin words of bitvec_pass)
     const long long bytes = ((W * 2 + 15) / 16) * 16;
     if (bytes > kRowSweepLdsCap) PBA_FAIL(PBA_E_TOOLONG, "band row does not fit the per-wavefront LDS budget");
     pl->cfg.R = R; pl->cfg.maxn = maxn; pl->cfg.maxm = maxm; pl->cfg.full_band = 0;

@@ -2,6 +2,8 @@
 """Turn gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/.
 usage: tools/summarise_profiles.py <tag> <round-prefix, e.g. r01>"""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pacbioassembly_amd import build as pba_build
 tag, rp = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
@@ -37,6 +39,8 @@ traffic = {"kernel": loc,
            "raw_fetch_bytes": int(h["FETCH_SIZE_KB_avg"] * 1024), "raw_write_bytes": int(h["WRITE_SIZE_KB_avg"] * 1024),
            "method": f"profiles/{rp}_bench_pmc_hbm.json: 2*FETCH_SIZE + WRITE_SIZE (gfx950 half-count correction applied to the read side)",
            "valu_insts_per_launch": s.get("SQ_INSTS_VALU"), "salu_insts_per_launch": s.get("SQ_INSTS_SALU"),
-           "gpu_cycles_per_launch": (s.get("GRBM_GUI_ACTIVE") or 0) / 8 or None, "round": int(rp[1:])}
+           "gpu_cycles_per_launch": (s.get("GRBM_GUI_ACTIVE") or 0) / 8 or None, "round": int(rp[1:]),
+           # the kernels these counters were collected on: bench.py drops the PMC-derived fields when the sources have changed
+           "source_digest": pba_build.source_digest()}
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(traffic))
