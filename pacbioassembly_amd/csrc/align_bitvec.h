@@ -371,9 +371,7 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
     }
     if (failed) {
         int fr = fail_row ? fail_row : INT_MAX;  // rows fail in increasing order of step: the smallest is the first
-#pragma unroll
-        for (int d = 1; d < PBA_WAVE; d <<= 1) fr = min(fr, __shfl_xor(fr, d, PBA_WAVE));
-        return __builtin_amdgcn_readfirstlane(fr);
+        return wave_min_i32(fr);
     }
     t_seg = INT_MAX - 1; t_dstart = INT_MAX;
     t_next = min(t_evt, t <= t_hin_end() ? t_hin_end() + 1 : INT_MAX);

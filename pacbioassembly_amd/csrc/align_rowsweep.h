@@ -109,12 +109,14 @@ __device__ void align_rowsweep(const FA &fa, int la, const FB &fb, int lb, doubl
             const int v = row[j - len_a + m];
             if (v < bv) { bv = v; bj = j; }
         }
-#pragma unroll
-        for (int d = 1; d < PBA_WAVE; d <<= 1) {
-            const int ov = __shfl_xor(bv, d, PBA_WAVE), oj = __shfl_xor(bj, d, PBA_WAVE);
-            if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-        }
-        o.matlen_a = len_a; o.matlen_b = __builtin_amdgcn_readfirstlane(bj); o.cost = __builtin_amdgcn_readfirstlane(bv);
+#define PBA_RS_STEP(d) { const int ov = PBA_SWZ_XOR(bv, d), oj = PBA_SWZ_XOR(bj, d); \
+                         if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; } }
+        PBA_RS_STEP(1) PBA_RS_STEP(2) PBA_RS_STEP(4) PBA_RS_STEP(8) PBA_RS_STEP(16)       // (dev_common.h on why not __shfl_xor)
+#undef PBA_RS_STEP
+        const int v0 = __builtin_amdgcn_readlane(bv, 0), j0 = __builtin_amdgcn_readlane(bj, 0);
+        const int v1 = __builtin_amdgcn_readlane(bv, 32), j1 = __builtin_amdgcn_readlane(bj, 32);
+        const bool hi = v1 < v0 || (v1 == v0 && j1 < j0);
+        o.matlen_a = len_a; o.matlen_b = hi ? j1 : j0; o.cost = hi ? v1 : v0;
     }
     // acceptance, seq_aligner.h:114
     o.rc = ((double)o.matlen_b < (double)len_b * (1.0 - R)) ? -1 : o.matlen_b;

@@ -22,6 +22,21 @@ struct SeqSetDev {
     const uint64_t *poff;    // word (pair) offset of sequence i
 };
 
+// Reductions over the 64 lanes through ds_swizzle (the partner lane is in the instruction): __shfl_xor builds a vector
+// of lane addresses per distance, which the compiler hoists out of the alignment loops and spills to scratch memory.
+// Every lane must be active; the result is wave-uniform.
+#define PBA_SWZ_XOR(v, d) __builtin_amdgcn_ds_swizzle((v), ((d) << 10) | 0x1F)
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, PBA_SWZ_XOR(v, 1)); v = min(v, PBA_SWZ_XOR(v, 2)); v = min(v, PBA_SWZ_XOR(v, 4));
+    v = min(v, PBA_SWZ_XOR(v, 8)); v = min(v, PBA_SWZ_XOR(v, 16));
+    return min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += PBA_SWZ_XOR(v, 1); v += PBA_SWZ_XOR(v, 2); v += PBA_SWZ_XOR(v, 4);
+    v += PBA_SWZ_XOR(v, 8); v += PBA_SWZ_XOR(v, 16);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 32);
+}
+
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
@@ -62,6 +77,16 @@ struct PackedFetch {
 // accessor on sequence `id` of a set (dna_seq.h:191: origin + direction)
 __device__ __forceinline__ PackedFetch fetch_of(const SeqSetDev &S, uint32_t id, int org, int dir) {
     return PackedFetch{S.packed + S.off[id], org, dir, S.plane + 2 * S.poff[id]};
+}
+// The same for an id every lane of the wavefront agrees on: the two offsets are forced into scalar registers (the
+// loads go through the vector path -- the compiler cannot prove the tables are not written by the kernel -- and their
+// results would otherwise sit in four vector registers per accessor for as long as the read is worked on).
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+}
+__device__ __forceinline__ PackedFetch fetch_of_uniform(const SeqSetDev &S, uint32_t id, int org, int dir) {
+    return PackedFetch{S.packed + uniform_u64(S.off[id]), org, dir, S.plane + 2 * uniform_u64(S.poff[id])};
 }
 struct ByteFetch {
     const uint8_t *org;   // accessor origin (pointer to element 0)

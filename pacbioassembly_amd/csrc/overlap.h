@@ -449,6 +449,7 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
     constexpr int WPB = NB ? 4 : 1;
     __shared__ uint32_t s2_fail[WPB][PBA_OVL_CHUNK][2];
     __shared__ uint16_t s2_list[WPB][PBA_OVL_S2_CAP];
+    __shared__ uint64_t s_cd[WPB][PBA_WAVE];           // the group in flight: kept here, not in registers, while the array has the wavefront
     const bool two_stage = NB != 0 && !redo_in;
     unsigned long long pairs = 0;
     for (;;) {
@@ -501,17 +502,19 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
         for (uint32_t item = base; item < item_end; ++item) {
         const uint32_t NONE = 0xFFFFFFFFu;
         uint32_t tl, c_begin, c_end, own_end, skip_q = NONE, only_q = NONE;
+        // (an item is the same in every lane: saying so keeps what describes it in scalar registers)
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
         if (redo_in) {
-            tl = redo_in[item].x; c_begin = redo_in[item].y; c_end = own_end = cand_off[tl] + cand_cnt[tl];
-            only_q = (uint32_t)(cand[c_begin] >> PBA_OVL_Q_SHIFT);
+            tl = uni(redo_in[item].x); c_begin = uni(redo_in[item].y); c_end = own_end = uni(cand_off[tl] + cand_cnt[tl]);
+            only_q = uni((uint32_t)(cand[c_begin] >> PBA_OVL_Q_SHIFT));
         } else {
-            tl = items[item].x; c_begin = items[item].y; c_end = cand_off[tl] + cand_cnt[tl];
+            tl = uni(items[item].x); c_begin = uni(items[item].y); c_end = uni(cand_off[tl] + cand_cnt[tl]);
             own_end = min(c_begin + (uint32_t)PBA_WAVE, c_end);
-            if (c_begin > cand_off[tl]) skip_q = (uint32_t)(cand[c_begin - 1] >> PBA_OVL_Q_SHIFT);   // a run begun in the previous group
+            if (c_begin > uni(cand_off[tl])) skip_q = uni((uint32_t)(cand[c_begin - 1] >> PBA_OVL_Q_SHIFT));   // a run begun in the previous group
         }
         const uint32_t t = t_lo + tl;
-        const PackedFetch ref = fetch_of(Rd, t, 0, 1);
-        const int ref_len = (int)Rd.len[t];
+        const PackedFetch ref = fetch_of_uniform(Rd, t, 0, 1);
+        const int ref_len = __builtin_amdgcn_readfirstlane((int)Rd.len[t]);
         const HeadTail ht(ref_len);
         uint32_t done_q = NONE, last_q = NONE;
         bool stop = false;
@@ -519,7 +522,7 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
         // group is walked in order and only the candidates that survived get the wavefront
         for (uint32_t c0 = c_begin; c0 < c_end && !stop; c0 += PBA_WAVE) {
             if (c0 >= own_end) {                                            // past the own group: only to finish its last run
-                const uint32_t nq = (uint32_t)(cand[c0] >> PBA_OVL_Q_SHIFT);
+                const uint32_t nq = uni((uint32_t)(cand[c0] >> PBA_OVL_Q_SHIFT));
                 if (nq != last_q || done_q == last_q || skip_q == last_q) break;
             }
             const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), ng = min((uint32_t)PBA_WAVE, c_end - c0);
@@ -541,6 +544,9 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             // Nearly every candidate has failed by now, so the group is not walked lane by lane: lane masks say where the
             // walk of this group ends, which failed candidates count as pairs, and only the survivors are visited.
             const uint32_t up_q = (uint32_t)__shfl_up((int)myq, 1, PBA_WAVE);
+            __builtin_amdgcn_wave_barrier();                                    // (the previous group's reads are done)
+            s_cd[wave][lane] = mycd;
+            __builtin_amdgcn_wave_barrier();
             const uint32_t prev_q = lane == 0 ? last_q : up_q;
             uint64_t brk = 0;                                                   // first lane the walk does not reach
             if (redo_in) brk = __builtin_amdgcn_ballot_w64(act && myq != only_q);           // the parked query's candidates are contiguous
@@ -555,7 +561,8 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             auto count_failed = [&](uint32_t to) {
                 if (to > from) {
                     const uint64_t f = failed & (to >= PBA_WAVE ? ~0ull : (1ull << to) - 1ull) & ~((1ull << from) - 1ull);
-                    if (f) pairs += (unsigned long long)__builtin_popcountll(f & __builtin_amdgcn_ballot_w64(myq != done_q));
+                    if (f) pairs += (unsigned long long)__builtin_popcountll(
+                               f & __builtin_amdgcn_ballot_w64((uint32_t)(s_cd[wave][lane] >> PBA_OVL_Q_SHIFT) != done_q));
                 }
             };
             while (surv) {
@@ -564,13 +571,12 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
                 count_failed(k);
                 from = k + 1;
                 const uint32_t c = c0 + k;
-                const uint64_t cd = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mycd >> 32), (int)k) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readlane((int)mycd, (int)k);
+                const uint64_t cd = uniform_u64(s_cd[wave][k]);
                 const uint32_t q = (uint32_t)(cd >> PBA_OVL_Q_SHIFT);
                 if (q == done_q) continue;                                  // first success per (target, query) already taken
-                const OvlCand mk = ovl_decode(Rd, ref_len, ht, cd, cfg);
+                const OvlCand mk = ovl_decode_len(__builtin_amdgcn_readfirstlane((int)Rd.len[q]), ref_len, ht, cd, cfg);
                 const PackedFetch fa = ref.at(mk.r_off, mk.fwd ? 1 : -1);    // a = the target in the reference role (ref_seq.h:264)
-                const PackedFetch fb = fetch_of(Rd, q, mk.s_off, mk.fwd ? 1 : -1);
+                const PackedFetch fb = fetch_of_uniform(Rd, q, mk.s_off, mk.fwd ? 1 : -1);
                 AlnOut o;
                 if constexpr (NB == 0) align_rowsweep(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
                 else align_bitvec<NB>(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);
@@ -586,7 +592,7 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
                 ovl_emit(out, cap, n_out, t, q, mk.j, mk.fwd, mk.hit, o);
             }
             count_failed(lim);
-            if (lim) last_q = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)(lim - 1));
+            if (lim) last_q = uni((uint32_t)(s_cd[wave][lim - 1] >> PBA_OVL_Q_SHIFT));
             if (brk) stop = true;
         }
         }

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(PBA_WAVE * Wpb<NB>::v, Wpb<NB>::occ)
 k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *ids, uint32_t n, int trials,
          int min_len, AlignCfg cfg, pba_loc_row *rows, LocAux *aux, uint32_t *queue) {
     extern __shared__ __align__(16) uint8_t lds_all[];
-    __shared__ int4 s_grp[Wpb<NB>::v][PBA_WAVE];      // the hit group in flight: position, failed-cell prefix (lo, hi)
+    __shared__ int2 s_grp[Wpb<NB>::v][PBA_WAVE];      // the hit group in flight: position, band cells of a hit the prefilter failed
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / PBA_WAVE));   // wave-uniform on purpose: keeps the walk in SGPRs
     uint8_t *lds = lds_all + (size_t)wave * cfg.row_cap * 2;
     const PreThresholds pre_t(cfg.R);
@@ -39,7 +39,7 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
     int found = 0, fj = -1, fpos = -1, fcost = -1, fma = 0, fmb = 0, fdiag = -1, npairs = 0, nhit = 0, redo = 0;
     long long ncell = 0;
     if (len >= min_len) {                                                   // locator.cpp:72
-        const PackedFetch rbase = fetch_of(Rd, r, 0, 1), tbase = fetch_of(T, tseq, 0, 1);
+        const PackedFetch rbase = fetch_of(Rd, r, 0, 1), tbase = fetch_of_uniform(T, tseq, 0, 1);
         const uint8_t *rseq = rbase.seq;
         const int clen = __builtin_amdgcn_readfirstlane((int)T.len[tseq]);
         for (int j = 0; j < trials && j < len && !found && !redo; ++j) {    // locator.cpp:74
@@ -66,30 +66,23 @@ k_locate(IndexDev ix, SeqSetDev T, uint32_t tseq, SeqSetDev Rd, const uint32_t *
                     mycells = myfr ? band_cells(po.len_b, po.max_dst, myfr) : 0;
                 }
                 // The group's per-lane state goes to LDS before the array takes the wavefront (kept in registers it was
-                // spilled to scratch memory around every alignment): the hit position, and the running sum of the band
-                // cells of the hits that failed in their first 32 rows -- the hits between two survivors are counted
-                // from those sums, in list order, up to the first success.
+                // spilled to scratch memory around every alignment): the hit position and the band cells of a hit that
+                // failed in its first 32 rows (<= 32 x 9001, so a group's sum fits 32 bits) -- the hits between two
+                // survivors are counted from there, in list order, up to the first success.
                 const uint64_t fmask = __builtin_amdgcn_ballot_w64(myfr != 0);
                 uint64_t surv = __builtin_amdgcn_ballot_w64(act && myfr == 0);
-                long long pc = mycells;                                 // inclusive prefix over the lanes
-#pragma unroll
-                for (int d = 1; d < PBA_WAVE; d <<= 1) {
-                    const long long up = ((long long)__shfl_up((int)(pc >> 32), d, PBA_WAVE) << 32) | (unsigned)__shfl_up((int)pc, d, PBA_WAVE);
-                    if ((int)lane >= d) pc += up;
-                }
                 __builtin_amdgcn_wave_barrier();                        // (the previous group's reads are done)
-                s_grp[wave][lane] = make_int4(mypos, (int)pc, (int)(pc >> 32), 0);
+                s_grp[wave][lane] = make_int2(mypos, (int)mycells);
                 __builtin_amdgcn_wave_barrier();
-                auto cells_upto = [&](uint32_t n_lanes) -> long long {  // failed cells of lanes [0, n_lanes)
-                    if (n_lanes == 0) return 0ll;
-                    const int4 g = s_grp[wave][n_lanes - 1];
-                    return ((long long)__builtin_amdgcn_readfirstlane(g.z) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(g.y);
-                };
                 uint32_t from = 0;
                 auto count_failed = [&](uint32_t to) {                  // hits [from, to) that failed: seq_aligner.h:185
                     if (to > from) {
                         const uint64_t m = fmask & (to >= PBA_WAVE ? ~0ull : (1ull << to) - 1ull) & ~((1ull << from) - 1ull);
-                        if (m) { npairs += __builtin_popcountll(m); ncell += cells_upto(to) - cells_upto(from); }
+                        if (m) {
+                            const uint32_t l = threadIdx.x & (PBA_WAVE - 1);
+                            npairs += __builtin_popcountll(m);
+                            ncell += (unsigned)wave_sum_i32(l >= from && l < to ? s_grp[wave][l].y : 0);
+                        }
                     }
                 };
                 while (surv) {
