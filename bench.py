@@ -68,6 +68,8 @@ def parse():
                     help="take the multi-GPU seed-index exchange path (scan slice -> RCCL all-gather -> build) even at N=1")
     ap.add_argument("--overlap-reads", type=int, default=200_000,
                     help="all-vs-all: reads of the WHOLE set (strong scaling); in locate mode the size of the extra leg, 0 = skip it")
+    ap.add_argument("--overlap-timeout", type=int, default=420,
+                    help="locate mode: seconds after which the extra all-vs-all leg is given up and the headline line printed without it")
     ap.add_argument("--coverage", type=float, default=20.0, help="all-vs-all: genome = reads x read_len / coverage")
     ap.add_argument("--overlap-trials", type=int, default=32)
     ap.add_argument("--targets-per-call", type=int, default=25_000)
@@ -160,6 +162,8 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
     import torch.distributed as dist
     from pacbioassembly_amd import ProbeTable, distributed as pd, engine as eng
 
+    if os.environ.get("PBA_BENCH_TEST_FAIL_RANK") == str(rank):       # tests: what a rank dying in this leg does to the line
+        raise RuntimeError("PBA_BENCH_TEST_FAIL_RANK: this rank fails in the all-vs-all leg")
     n, rl, trials = a.overlap_reads, a.read_len, a.overlap_trials
     L = int(n * rl / a.coverage)
     mask = eng.mask_from_pattern(MASK_PAT)
@@ -256,6 +260,39 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
                           "frac": round(scan_bytes / world / scan_s / HBM_PEAK, 5) if scan_s > 0 else None,
                           "note": "per GPU: 0.25 B per visited position + 8 B per candidate written, over the slowest rank's scan time"},
     }
+
+
+def guarded_overlap(a, ctx, rank, world, nthreads, headline):
+    """The all-vs-all leg of a default run, fenced off from the headline line: whatever happens in it -- an exception on
+    this rank, or a collective that never returns because another rank failed -- rank 0 still prints `headline` (with the
+    error noted in `overlap_strong`) and every rank leaves with exit code 0.  headline: rank 0's finished line, None elsewhere."""
+    import threading
+    if a.overlap_reads <= 0:
+        return None
+    done = threading.Event()
+
+    def leave(msg):
+        if headline is not None:
+            headline["overlap_strong"] = {"error": msg}
+            print(json.dumps(headline), flush=True)
+        os._exit(0)                                   # no teardown of a process group that may be wedged
+
+    def watchdog():
+        if not done.is_set():
+            leave(f"the all-vs-all leg did not finish within {a.overlap_timeout} s on rank {rank}")
+
+    timer = threading.Timer(a.overlap_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
+    try:
+        ov = overlap_leg(a, ctx, rank, world, nthreads, 1, 1)
+    except BaseException as e:                        # noqa: BLE001 -- the headline line must not depend on this leg
+        if world > 1:
+            leave(f"rank {rank}: {type(e).__name__}: {e}")       # the other ranks are left to their watchdogs
+        ov = {"error": f"{type(e).__name__}: {e}"}
+    done.set()
+    timer.cancel()
+    return ov
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -372,19 +409,12 @@ def run_rank(a):
     else:
         pairs, located, cells = st["n_pairs"], st["n_located"], st["n_cells"]
 
-    # ---- the all-vs-all leg (strong scaling), after the timed region of the headline metric
-    overlap = None
-    if a.overlap_reads > 0:
-        Rd.close()
-        T.close()
-        try:
-            overlap = overlap_leg(a, ctx, rank, world, nthreads, 1, 1)
-        except Exception as e:                                           # the headline line must not depend on it
-            if world > 1:
-                raise
-            overlap = {"error": f"{type(e).__name__}: {e}"}
-
+    # ---- the all-vs-all leg (strong scaling) runs after the timed region of the headline metric, and after rank 0 has
+    # put the headline line together (guarded_overlap below): nothing it does can cost the run its headline line
+    Rd.close()
+    T.close()
     if rank != 0:
+        guarded_overlap(a, ctx, rank, world, nthreads, None)
         dist.destroy_process_group()
         return
 
@@ -482,9 +512,10 @@ def run_rank(a):
                       "locate_redo": round(redo_ms, 3), "n_redo_reads": profs[-1]["n_redo"]},
         "setup_s": {"generate": round(t_gen, 2), "upload_and_pack": round(t_up, 2)},
         "source_digest": pba_build.source_digest(),
-        "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "overlap_strong": overlap,
+        "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "overlap_strong": None,
     }
-    print(json.dumps(out))
+    out["overlap_strong"] = guarded_overlap(a, ctx, rank, world, nthreads, out)
+    print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -1313,3 +1313,12 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
         assert a[k] == b[k] > 1000, k
     ovl = run("--gpus", "2", "--backend", "gloo", "--mode", "overlap")
     assert ovl["scaling"] == "strong" and ovl["overlap"]["pairs_per_step"] == b["pairs_per_step"]
+    # a rank that dies in the extra all-vs-all leg costs the run that leg, not its headline line: the failing rank leaves,
+    # the other one gives the leg up at its timeout, rank 0 prints the line with the error noted, exit code 0
+    for bad in ("1", "0"):
+        env["PBA_BENCH_TEST_FAIL_RANK"] = bad
+        hurt = run("--gpus", "2", "--backend", "gloo", "--overlap-timeout", "25")
+        assert hurt["n_gpus"] == 2 and hurt["pairs_per_step"] == two["pairs_per_step"]
+        assert "error" in hurt["overlap_strong"], hurt["overlap_strong"]
+    del env["PBA_BENCH_TEST_FAIL_RANK"]
+
