@@ -53,8 +53,9 @@ MASK_PAT = "111*11*11*1*1111"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3,
+                    help="untimed steps first (one of the first three calls on a fresh process takes ~25 ms longer on the host side)")
     ap.add_argument("--mode", choices=["locate", "overlap"], default="locate")
     ap.add_argument("--reads", type=int, default=100_000, help="locate mode: reads per GPU")
     ap.add_argument("--read-len", type=int, default=15_000)
@@ -394,11 +395,17 @@ def run_rank(a):
     fence()
     t0 = time.perf_counter()
     profs = []
+    step_wall = []
     for _ in range(a.steps):
+        t_s = time.perf_counter()
         rows, st, prof = step()
         profs.append(prof)
+        step_wall.append(time.perf_counter() - t_s)
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PBA_BENCH_VERBOSE"):
+        print(f"rank {rank}: step wall ms {[round(1e3 * x, 2) for x in step_wall]}, kernel ms "
+              f"{[round(p['align_ms'], 2) for p in profs]}", file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -151,6 +151,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int k) {
 // state and the two hand-off masks go to tr (bv_ck_words per chunk, 1/25 of the streamed words); the walk re-runs one
 // chunk at a time from its checkpoint into LDS (align_bvtrace.h: bitvec_rerun).
 #define PBA_BV_CK_WORDS(nb) ((nb) * 128 + 128)
+#define PBA_BV_BAIL 0x40000000                         // bitvec_pass: "not worth finishing in this window" (above any row number)
 template <int NB>
 __device__ __forceinline__ void bv_ckpt_store(uint32_t *tr, int tb, int lane, const uint32_t *Pv, const uint32_t *Mv, int s_cur,
                                               uint32_t opened, uint64_t hp_last, uint64_t hn_last) {
@@ -162,10 +163,15 @@ __device__ __forceinline__ void bv_ckpt_store(uint32_t *tr, int tb, int lane, co
         ck[NB * 128 + 64 + lane] = lane == 0 ? (uint32_t)hp_last : lane == 1 ? (uint32_t)(hp_last >> 32) : lane == 2 ? (uint32_t)hn_last : (uint32_t)(hn_last >> 32);
 }
 
-template <int NB, int TRACE = 0>
+template <int NB, int TRACE = 0, bool BAIL = false>
 __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, const PackedFetch &colsF, int m, int wleft, int w,
                                            double R, int &best_out, int &besti_out, int &diag_out, uint32_t *fin,
-                                           uint32_t *tr = nullptr, bool swap_roles = false) {
+                                           uint32_t *tr = nullptr, bool swap_roles = false, int bail_w = 0) {
+    // BAIL and bail_w > 0: give the sweep up (return PBA_BV_BAIL) once the diagonal says where the pair is heading -- at row i >= 1024,
+    // (D(i,i) - 4 sqrt(D(i,i))) * m / i > bail_w (four standard deviations of a count of D(i,i) errors below the projection:
+    // a pair that will come in under bail_w is not given up by accident; the check runs at every 32nd row): a cost the
+    // window could not certify anyway (align_bitvec: the caller re-runs the pair with the
+    // reference's band either way; this only decides how many rows the narrow sweep spends finding out).  Never changes a result.
     // rowsF / nr: the longer sequence and how many of its rows are swept (m <= nr <= m + wleft); colsF / m: the shorter
     // one.  Row i sees the columns [i - wleft, i + w] (wleft: the wide side, towards the free end; w: the narrow one).
     constexpr int RB = 32 * NB;                 // rows per superblock
@@ -249,6 +255,10 @@ __device__ __forceinline__ int bitvec_pass(const PackedFetch &rowsF, int nr, con
                 const int d = score + k - __builtin_popcount(dw & (0xFFFFFFFFu >> (32 - k)));
                 if ((double)d > (double)(i0 + k) * R) { fail_row = i0 + k; break; }
             }
+        }
+        if constexpr (BAIL) {
+            if (bail_w > 0 && i >= 1024 && fail_row == 0 &&
+                ((float)end - 4.0f * __builtin_sqrtf((float)end)) * (float)m > (float)i * (float)bail_w) fail_row = PBA_BV_BAIL;
         }
         score = end;
 #pragma unroll
@@ -498,7 +508,10 @@ __device__ __forceinline__ bool bv_goal_certified(int best, int wl, int w, int m
 // lds: PBA_BV_FIN_WORDS(NB) u32 of this wavefront's own (>= 256 bytes: the m <= 10 corner runs the row sweep in it)
 // need_diag: the caller reports D(m,m) (locator.cpp:86): a narrow pass whose window cannot vouch for that cell too
 // answers PBA_RC_UNCERTIFIED; without it o.diag is -1 in that case.
-template <int NB>
+// BAIL: give a narrow first pass up early when the pair is heading for a cost its window cannot certify (bitvec_pass:
+// bail_w).  For callers whose true pairs are expected beyond the first-pass window (the all-vs-all walk: two noisy reads);
+// compiled out elsewhere -- the test costs the step loop three scalar registers, 6 % of k_locate's time at 8 waves per SIMD.
+template <int NB, bool BAIL = false>
 __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, const PackedFetch &fb, int lb, double R,
                                              int maxn, int maxm, bool full_band, uint16_t *lds, int lds_cells,
                                              AlnOut &o, bool need_diag = false) {
@@ -516,9 +529,15 @@ __device__ __forceinline__ void align_bitvec(const PackedFetch &fa, int la, cons
     if (wl + w > bv_max_span(NB)) { o.rc = -2; return; }   // host sizes NB for the launch: cannot happen
     const PackedFetch rowsF = a_rows ? fa : fb, colsF = a_rows ? fb : fa;
     int best = 0, besti = 0, diag = 0;
-    const int fr = bitvec_pass<NB>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag, (uint32_t *)lds);
+    // A narrow window certifies a goal minimum <= w only: a pair whose diagonal is heading past that (two noisy reads of an
+    // all-vs-all run differ by ~28 %, against a window sized for a read against its genome) is given up after ~1000 rows
+    // instead of being swept to the end for an answer nobody can use.
+    const int bail_w = (BAIL && !full_band && w < md) ? w : 0;
+    const int fr = bitvec_pass<NB, 0, BAIL>(rowsF, min(n, m + w), colsF, m, w, wl, R, best, besti, diag, (uint32_t *)lds, nullptr, false, bail_w);
     if (fr) {
-        if (bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
+        bool gave_up = false;
+        if constexpr (BAIL) gave_up = fr == PBA_BV_BAIL;
+        if (!gave_up && bv_fail_certified(fr, R, wl, md)) o.fail_row = fr; else o.rc = PBA_RC_UNCERTIFIED;
         return;
     }
     if (!bv_goal_certified(best, wl, w, md)) { o.rc = PBA_RC_UNCERTIFIED; return; }   // header comment

@@ -579,7 +579,7 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
                 const PackedFetch fb = fetch_of_uniform(Rd, q, mk.s_off, mk.fwd ? 1 : -1);
                 AlnOut o;
                 if constexpr (NB == 0) align_rowsweep(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, lds, cfg.row_cap, o);
-                else align_bitvec<NB>(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);
+                else align_bitvec<NB, true>(fa, mk.r_len, fb, mk.s_len, cfg.R, 0, 0, full_band != 0, lds, cfg.row_cap, o);
                 if (o.rc == PBA_RC_UNCERTIFIED) {                           // park the (target, query): resumed in a wider ring
                     done_q = q;
                     const unsigned long long slot = atomicAdd(n_redo_out, l0 ? 1ull : 0ull);
