@@ -63,7 +63,13 @@ print(json.dumps({"workload": f"traceback of {hit.size} true {a.read_len}-base p
                   "checkpoint_bytes_per_pair": int(ck_bytes),
                   "pairs": int(hit.size), "kernel_ms": round(ms, 2), "wall_s_with_d2h": round(best[1], 3),
                   "scripts_per_s": round(hit.size / (ms / 1e3), 1), "mean_nedit": float(nedit.mean()), "nb": nb,
-                  "parent_bits_bytes_per_pair": int(stream), "hbm_write_GBps": round(hit.size * stream / (ms / 1e3) / 1e9, 1),
-                  "frac_of_8TBps": round(hit.size * stream / (ms / 1e3) / 8e12, 4),
+                  "parent_bits_bytes_per_pair": int(stream),
+                  # what the kernel really moves: the stream form writes the parent words, the checkpoint form its checkpoints
+                  "stored_bytes_per_pair": int(stream if stream_form else ck_bytes),
+                  "stored_GBps": round(hit.size * (stream if stream_form else ck_bytes) / (ms / 1e3) / 1e9, 1),
+                  "stored_frac_of_8TBps": round(hit.size * (stream if stream_form else ck_bytes) / (ms / 1e3) / 8e12, 4),
+                  # the rate a kernel that streamed the parent bits would have needed for the same scripts/s (above the HBM
+                  # peak in the checkpoint form: not writing them is what the form is for; it is bound by recomputation)
+                  "parent_bits_equivalent_GBps": round(hit.size * stream / (ms / 1e3) / 1e9, 1),
                   "survey_fig_bytes_per_pair(cells/4)": int(cells_ref / 4),
-                  "survey_fig_GBps": round(hit.size * cells_ref / 4 / (ms / 1e3) / 1e9, 1)}))
+                  "survey_fig_equivalent_GBps": round(hit.size * cells_ref / 4 / (ms / 1e3) / 1e9, 1)}))

@@ -2,16 +2,22 @@
 """Turn gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/.
 usage: tools/summarise_profiles.py <tag> <round-prefix, e.g. r01>"""
 import collections, csv, glob, json, os, shutil, sys
+
+
+def newest(pattern):
+    """a re-run into the same tag leaves the older run's files beside the new ones: take the latest"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pacbioassembly_amd import build as pba_build
 tag, rp = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"profiles/{rp}_bench_kernel_stats.csv")
+shutil.copy(newest(f"{src}/trace/*/*_kernel_stats.csv"), f"profiles/{rp}_bench_kernel_stats.csv")
 shutil.copy(f"{src}/bench_trace.json", f"profiles/{rp}_bench_under_rocprof.json")
 
 def counters(sub):
-    f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")
+    f = sorted(glob.glob(f"{src}/{sub}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f[0])):
