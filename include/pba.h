@@ -400,6 +400,8 @@ typedef struct {
     uint32_t wide_first;           /* 1: a sample showed the narrow window rarely certifies, the rest went straight to the reference band */
     float table_ms;                /* build of the probe table this call scanned against (once per table, not per call) */
     uint32_t n_big_targets;        /* targets whose candidates outgrew one LDS sort and were cut into pieces of consecutive queries */
+    uint64_t n_prefiltered;        /* candidates of n_pairs that were dropped before the sort: every candidate of their (target, query)
+                                      run failed the reference's diagonal check within its first 32 rows (big calls only, else 0) */
 } pba_overlap_stats;
 
 /* Limits of the all-vs-all entry points (explicit PBA_E_TOOLONG beyond them, never a wrapped count):

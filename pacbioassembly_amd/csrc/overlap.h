@@ -415,6 +415,125 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
     }
 }
 
+// ---- the first prefilter stage BEFORE the sort (big calls)
+// 98.6 % of the candidates fail their first 32 rows (prefilter.h), and all a failed candidate ever contributes is +1 to the
+// pair count -- unless its (target, query) run has a success before it, in which case the reference never tried it.  A run
+// with a success has a candidate that passes the prefilter.  So: k_ovl_pre runs the first stage over the UNSORTED slices
+// and sets, per target, a bit for the query of every candidate that passes (a Bloom filter with one hash: 2^15 bits per
+// target); k_ovl_keep then keeps the candidates whose query has its bit set -- every run that can hold a success, whole
+// and therefore still in the reference's order once sorted, plus a few per cent of false positives -- and the rest, runs
+// in which every candidate failed its first 32 rows, are pairs the reference aligned and dropped: counted, not sorted, not
+// walked.  Sort and walk then see ~3-5 % of the list and do with it exactly what they did with all of it.
+// Candidates the walk would skip before the aligner (OvlCand::ok false) are blanked here.
+#define PBA_OVL_BLOOM_BITS 15
+#define PBA_OVL_BLOOM_WORDS (1u << (PBA_OVL_BLOOM_BITS - 5))
+__device__ __forceinline__ uint32_t ovl_bloom_slot(uint32_t q) { return (q * 0x9E3779B1u) >> (32 - PBA_OVL_BLOOM_BITS); }
+
+// What the stage needs of a QUERY is its length and 32 bases next to one of its ends (a probe sits at offset j <= 31 from
+// the start, or from the end walking left): through the read set that is three scattered lines per candidate (length,
+// plane offset, plane words) -- at a million reads mostly from HBM.  The ends of every read are therefore put side by side
+// once per call: one 64-byte line per read, 64 MB at a million reads (Infinity-Cache resident), one line per candidate.
+struct __attribute__((aligned(32))) OvlEnd {
+    uint32_t len, pad;
+    uint64_t lo, hi;      // bit planes of 64 bases: [0] the first 64 (bit b = base b), [1] the last 64 (bit b = base len - 64 + b)
+};
+static __global__ void __launch_bounds__(256)
+k_ovl_ends(SeqSetDev Rd, uint32_t n, OvlEnd *ends) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int len = (int)Rd.len[q];
+    const PackedFetch f = fetch_of(Rd, q, 0, 1);
+    OvlEnd h = {(uint32_t)len, 0u, 0ull, 0ull}, t = h;
+    if (len >= 64) {
+        uint32_t l0, h0, l1, h1;
+        load_planes32(f, 0, l0, h0); load_planes32(f, 32, l1, h1);
+        h.lo = (uint64_t)l1 << 32 | l0; h.hi = (uint64_t)h1 << 32 | h0;
+        load_planes32(f, len - 64, l0, h0); load_planes32(f, len - 32, l1, h1);
+        t.lo = (uint64_t)l1 << 32 | l0; t.hi = (uint64_t)h1 << 32 | h0;
+    }
+    ends[2 * (size_t)q] = h; ends[2 * (size_t)q + 1] = t;
+}
+
+// one wavefront per item = (target, 64 consecutive slots of its unsorted slice; cand_off[t + 1] ends the slice)
+static __global__ void __launch_bounds__(256)
+k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, uint64_t *cand, OvlCfg cfg,
+          PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, uint32_t *n_blanked) {
+    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
+    if (item >= n_items) return;
+    const uint2 it = items[item];
+    const uint32_t c = it.y + lane;
+    const uint64_t cd = c < cand_off[it.x + 1] ? cand[c] : ~0ull;
+    const uint32_t t = t_lo + it.x;
+    const int ref_len = (int)Rd.len[t];
+    const HeadTail ht(ref_len);
+    const bool have = cd != ~0ull;
+    const uint64_t cdv = have ? cd : 0ull;
+    const bool bwd = (cdv >> PBA_OVL_ORD_BITS) & 1ull;
+    const OvlEnd er = ends[2 * (size_t)(uint32_t)(cdv >> PBA_OVL_Q_SHIFT) + (bwd ? 1 : 0)];
+    const OvlCand m = ovl_decode_len((int)er.len, ref_len, ht, cdv, cfg);
+    const bool blank = have && !m.ok;
+    if (blank) cand[c] = ~0ull;
+    const uint64_t bm = __builtin_amdgcn_ballot_w64(blank);
+    if (bm) atomicAdd(&n_blanked[it.x], lane == 0 ? (uint32_t)__builtin_popcountll(bm) : 0u);
+    AlnOut po;
+    int fr = 0;
+    if (prefilter32_applies(have && m.ok, m.r_len, m.s_len, cfg.R, 0, 0, po)) {
+        uint32_t alo, ahi, blo, bhi;
+        load_planes32(fetch_of(Rd, t, m.r_off, m.fwd ? 1 : -1), 0, alo, ahi);           // rows: the target from its hit
+        if (er.len >= 64 && m.j <= 32) {                                                // columns: the query's 32 bases, from its end record
+            // forward: element r = base j + r = head bit j + r; backward: element r = base len - j - 1 - r = tail bit 63 - j - r
+            const int sh = m.fwd ? m.j : 32 - m.j;
+            blo = (uint32_t)(er.lo >> sh); bhi = (uint32_t)(er.hi >> sh);
+            if (!m.fwd) { blo = __builtin_bitreverse32(blo); bhi = __builtin_bitreverse32(bhi); }
+        } else load_planes32(fetch_of(Rd, m.q, m.s_off, m.fwd ? 1 : -1), 0, blo, bhi);
+        fr = prefilter32_planes(alo, ahi, blo, bhi, pre_t);
+    }
+    if (have && m.ok && fr == 0) {
+        const uint32_t s = ovl_bloom_slot(m.q);
+        atomicOr(&bloom[(size_t)it.x * PBA_OVL_BLOOM_WORDS + (s >> 5)], 1u << (s & 31u));
+    }
+}
+
+// same items: the candidates whose query has its bit set are packed densely, target after target, into a second buffer (in
+// any order inside a target: they are sorted next).  Count per item, prefix sums over the items (k_scan_*), write -- a
+// cursor per target moved with atomics instead had every wavefront of the chip on the same few words (the items of a
+// target run together): 84 s of a 7.9 s run at a million reads.
+__device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, uint32_t tl, uint64_t cd) {
+    if (cd == ~0ull) return false;
+    const uint32_t s = ovl_bloom_slot((uint32_t)(cd >> PBA_OVL_Q_SHIFT));
+    return (bloom[(size_t)tl * PBA_OVL_BLOOM_WORDS + (s >> 5)] >> (s & 31u)) & 1u;
+}
+// kept_of[item] = candidates of the item that stay
+static __global__ void __launch_bounds__(256)
+k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint32_t *bloom,
+                 uint32_t *kept_of) {
+    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
+    if (item >= n_items) return;
+    const uint2 it = items[item];
+    const uint32_t c = it.y + lane;
+    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, it.x, c < cand_off[it.x + 1] ? cand[c] : ~0ull));
+    if (lane == 0) kept_of[item] = (uint32_t)__builtin_popcountll(km);
+}
+// kept_before[item] = candidates kept by the items before it (kept_before[n_items] = all of them)
+static __global__ void __launch_bounds__(256)
+k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint32_t *bloom,
+                 const uint32_t *kept_before, uint64_t *kept) {
+    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
+    if (item >= n_items) return;
+    const uint2 it = items[item];
+    const uint32_t c = it.y + lane;
+    const uint64_t cd = c < cand_off[it.x + 1] ? cand[c] : ~0ull;
+    const bool keep = ovl_kept(bloom, it.x, cd);
+    const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+    if (keep) kept[kept_before[item] + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = cd;
+}
+// where every target's kept candidates start in the packed list: the prefix sum at its first item
+static __global__ void __launch_bounds__(256)
+k_ovl_keep_offsets(const uint32_t *item_pre, const uint32_t *kept_before, uint32_t n_targets, uint32_t *kept_off) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n_targets) kept_off[t] = kept_before[item_pre[t]];
+}
+
 // First launch (redo_in == nullptr): persistent wavefronts pull work items = (target, group of 64 consecutive
 // candidates) and walk them with the narrow window (NB = 0: row sweep).  Candidates of one (target, query) are
 // consecutive and must be tried in order, so a group owns the runs that START in it: it skips a leading run begun in

@@ -104,7 +104,7 @@ static const size_t kSlack = 1024;              // readable bytes before the fir
 
 // pool slots
 enum { POOL_OVL_CAND = 0, POOL_OVL_TMP, POOL_OVL_ITEMS, POOL_OVL_REDO, POOL_OVL_REDO_IN, POOL_OVL_OUT, POOL_OVL_SMALL,
-       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_OFFS, POOL_IX_WORK };
+       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_OFFS, POOL_IX_WORK, POOL_OVL_BLOOM, POOL_OVL_ENDS };
 // a buffer of at least `bytes` in pool slot `slot` (contents undefined); grows by reallocation with 1/8 headroom
 static inline int pool_reserve(pba_ctx *ctx, int slot, size_t bytes, void **out) {
     if (ctx->pool[slot].cap < bytes) {

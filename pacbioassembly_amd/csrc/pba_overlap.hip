@@ -19,7 +19,7 @@ extern "C" {
 #define PBA_OVL_WALK(NBV)                                                                                             \
     hipLaunchKernelGGL((k_ovl_walk<NBV>), dim3(persistent_grid(ctx, n_items, (NBV) ? 4 : 1, lds)),                        \
                        dim3(PBA_WAVE * ((NBV) ? 4 : 1)), lds * ((NBV) ? 4 : 1), ctx->stream, reads->dev(), t_lo, n_items,  \
-                       items, d_off.as<uint32_t>(), d_valid.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, full_band,       \
+                       items, d_woff, d_wcnt, d_cand.as<uint64_t>(), ocfg, full_band,                                    \
                        redo_in, d_redo.as<uint2>(),                                                                      \
                        (unsigned long long)redo_cap, d_cnt64.as<unsigned long long>() + 2, d_out.as<pba_overlap>(),     \
                        (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1,  \
@@ -236,6 +236,70 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     }
     (void)hipEventRecord(ctx->ev[3], ctx->stream);
 
+    // 2b. big calls on the bit-vector kernels: the first prefilter stage before the sort (overlap.h: k_ovl_pre / k_ovl_keep).
+    //     What is kept goes packed into the second buffer; the sort below moves it back, sorted; everything after sees the
+    //     packed list (h_koff / h_kept) where it saw the slices (h_off / h_valid).  The time is the sort's in the statistics.
+    uint64_t prekeep_min = 1ull << 22;
+    if (const char *e = getenv("PBA_OVL_PREKEEP_MIN")) prekeep_min = (uint64_t)std::max(0LL, atoll(e));   // test hook: small inputs through the stage (or none)
+    const bool prekeep = pl.nb1 != 0 && total >= prekeep_min && total > 0;
+    OvlCfg ocfg;
+    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
+    std::vector<uint32_t> h_kept, h_koff;                        // per target: candidates kept, and where they start in the packed list
+    uint32_t *d_koff = nullptr;
+    uint64_t n_dropped = 0;
+    BufRef d_items;
+    if (prekeep) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));               // h_valid
+        std::vector<uint32_t> h_ipre1(nt + 1);
+        uint64_t n_it = 0;
+        for (uint32_t i = 0; i < nt; ++i) { h_ipre1[i] = (uint32_t)n_it; n_it += (h_slice[i] + PBA_WAVE - 1) / PBA_WAVE; }
+        if (n_it >= 0xFFFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: too many work items per call, use a smaller target range");
+        h_ipre1[nt] = (uint32_t)n_it;
+        uint32_t *d_ipre1 = d_small.as<uint32_t>() + 3 * ((size_t)nt + 1);
+        HIPCHK(hipMemcpyAsync(d_ipre1, h_ipre1.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+        POOL(POOL_OVL_ITEMS, sizeof(uint2) * (n_it + 1), d_items.p);
+        hipLaunchKernelGGL(k_ovl_items, dim3((uint32_t)((n_it + 255) / 256)), dim3(256), 0, ctx->stream, d_ipre1, d_off.as<uint32_t>(), nt,
+                           (uint32_t)n_it, d_items.as<uint2>());
+        // per target: the Bloom words, its blanked count; per item: the kept counts (+1: exclusive prefix sums); per target + 1:
+        // the offsets into the packed list
+        BufRef d_bloom;
+        const size_t bloom_words = (size_t)nt * PBA_OVL_BLOOM_WORDS;
+        const uint32_t n_tiles = (uint32_t)((n_it + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
+        POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles), d_bloom.p);
+        HIPCHK(hipMemsetAsync(d_bloom.p, 0, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + 1), ctx->stream));
+        uint32_t *const d_blanked = d_bloom.as<uint32_t>() + bloom_words;
+        d_koff = d_blanked + (nt + 1);
+        uint32_t *const d_before = d_koff + (nt + 1);            // [n_it + 1], [0] = 0 (the memset above reaches it)
+        uint32_t *const d_tiles = d_before + n_it + 1;
+        POOL(POOL_OVL_TMP, sizeof(uint64_t) * (total + 1), d_tmp.p);
+        BufRef d_ends;                                           // the ends of every read side by side (overlap.h: OvlEnd)
+        POOL(POOL_OVL_ENDS, sizeof(OvlEnd) * 2 * (size_t)n, d_ends.p);
+        hipLaunchKernelGGL(k_ovl_ends, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reads->dev(), n, d_ends.as<OvlEnd>());
+        const uint32_t g = (uint32_t)((n_it + 3) / 4);
+        hipLaunchKernelGGL(k_ovl_pre, dim3(g), dim3(256), 0, ctx->stream, reads->dev(), t_lo, (uint32_t)n_it, d_items.as<uint2>(),
+                           d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), d_blanked);
+        hipLaunchKernelGGL(k_ovl_keep_count, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
+                           d_cand.as<uint64_t>(), d_bloom.as<uint32_t>(), d_before + 1);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
+        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
+        hipLaunchKernelGGL(k_ovl_keep_write, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
+                           d_cand.as<uint64_t>(), d_bloom.as<uint32_t>(), d_before, d_tmp.as<uint64_t>());
+        hipLaunchKernelGGL(k_ovl_keep_offsets, dim3((nt + 256) / 256), dim3(256), 0, ctx->stream, d_ipre1, d_before, nt, d_koff);
+        h_koff.resize(nt + 1);
+        std::vector<uint32_t> h_blanked(nt + 1);
+        HIPCHK(hipMemcpyAsync(h_koff.data(), d_koff, sizeof(uint32_t) * (nt + 1), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h_blanked.data(), d_blanked, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        h_kept.resize(nt + 1);
+        for (uint32_t i = 0; i < nt; ++i) {
+            h_kept[i] = h_koff[i + 1] - h_koff[i];
+            n_dropped += (uint64_t)h_valid[i] - h_blanked[i] - h_kept[i];
+        }
+        st.n_prefiltered = n_dropped;
+    }
+
     // 3. sort every target's slice = the reference's try order inside every (target, query): in LDS, in place; the big
     //    ones piece by piece through a second buffer
     if (total) {
@@ -247,10 +311,18 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         HIPCHK(hipMalloc(&d_ov.p, sizeof(uint32_t) * (1 + ov_cap) * 2));
         uint32_t *const ov_small = d_ov.as<uint32_t>(), *const ov_piece = ov_small + 1 + ov_cap;
         HIPCHK(hipMemsetAsync(d_ov.p, 0, sizeof(uint32_t) * (1 + ov_cap) * 2, ctx->stream));
+        std::vector<SegRef> h_pieces;
+        if (prekeep) {
+            // the packed list, target after target, from the second buffer into the candidate array, sorted; a target that kept
+            // more than one sort holds (tandem repeats) is copied by the kernel and listed for the global pass
+            uint32_t biggest = 2;
+            for (uint32_t i = 0; i < nt; ++i) biggest = std::max(biggest, h_kept[i]);
+            launch_seg_sort(ctx, d_tmp.as<uint64_t>(), d_cand.as<uint64_t>(), d_koff, nullptr, nt,
+                            std::min<uint32_t>(biggest, PBA_IX_LDS_SORT_CAP), seg_bkt_range(), ov_small, ov_cap);
+        } else
         launch_seg_sort(ctx, d_cand.as<uint64_t>(), d_cand.as<uint64_t>(), d_off.as<uint32_t>(), nullptr, nt,
                         big.empty() ? biggest_small : 0xFFFFFFFFu, seg_bkt_range(), ov_small, ov_cap);
-        std::vector<SegRef> h_pieces;
-        if (!big.empty()) {
+        if (!prekeep && !big.empty()) {
             st.n_big_targets = (uint32_t)big.size();
             DevBuf d_big, d_pieces, d_pc;
             const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // fine bucket = umulhi(q, sub_mul)
@@ -288,8 +360,9 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
             return v;
         };
         for (uint32_t i : listed(h_ov.data(), nt))                    // small slices with an overfull bucket (the big ones are cut into pieces)
-            if (h_slice[i] > 1 && h_slice[i] <= PBA_IX_LDS_SORT_CAP) {
-                rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], h_slice[i]);
+            if (prekeep ? h_kept[i] > 1 : (h_slice[i] > 1 && h_slice[i] <= PBA_IX_LDS_SORT_CAP)) {
+                rc = prekeep ? sort_partition_global(ctx, d_cand.as<uint64_t>() + h_koff[i], h_kept[i])
+                             : sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], h_slice[i]);
                 if (rc != PBA_OK) return rc;
             }
         for (uint32_t i : listed(h_ov.data() + 1 + ov_cap, h_pieces.size()))   // pieces beyond one sort, or with an overfull bucket
@@ -310,18 +383,27 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     POOL(POOL_OVL_OUT, sizeof(pba_overlap) * (cap + 1), d_out.p);
     HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 32, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
-    OvlCfg ocfg;
-    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
     const size_t lds = pl.lds;
-    BufRef d_redo, d_items;
+    BufRef d_redo;
+    const std::vector<uint32_t> &h_wcnt = prekeep ? h_kept : h_valid;      // what the walk sees of every target
+    // (the walk takes a count per target: with the packed list, target t's is the distance to the next offset)
+    BufRef d_kcnt;
+    if (prekeep) {
+        d_kcnt.p = d_small.as<uint32_t>() + 2 * ((size_t)nt + 1);            // d_valid's place: its host copy is what is used from here on
+        HIPCHK(hipMemcpyAsync(d_kcnt.p, h_kept.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const uint32_t *const d_wcnt = prekeep ? d_kcnt.as<uint32_t>() : d_valid.as<uint32_t>();
+    const uint32_t *const d_woff = prekeep ? d_koff : d_off.as<uint32_t>();
+    uint64_t n_walk = 0;
+    for (uint32_t i = 0; i < nt; ++i) n_walk += h_wcnt[i];
     // every (target, query) run can park at most once per stage, and there are no more runs than candidates
-    const uint64_t redo_cap = std::max<uint64_t>(1024, n_valid);
+    const uint64_t redo_cap = std::max<uint64_t>(1024, n_walk);
     POOL(POOL_OVL_REDO, sizeof(uint2) * redo_cap, d_redo.p);
     // work items: (target, first candidate of a group of 64), expanded on the device from the per-target item counts
     // (a million reads make 22 M items per call: building and copying them from the host took longer than a scan pass)
     std::vector<uint32_t> h_ipre(nt + 1);
     uint64_t n_items64 = 0;
-    for (uint32_t i = 0; i < nt; ++i) { h_ipre[i] = (uint32_t)n_items64; n_items64 += (h_valid[i] + PBA_WAVE - 1) / PBA_WAVE; }
+    for (uint32_t i = 0; i < nt; ++i) { h_ipre[i] = (uint32_t)n_items64; n_items64 += (h_wcnt[i] + PBA_WAVE - 1) / PBA_WAVE; }
     if (n_items64 >= 0xFFFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: too many work items per call, use a smaller target range");
     h_ipre[nt] = (uint32_t)n_items64;
     BufRef d_ipre;
@@ -330,7 +412,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     POOL(POOL_OVL_ITEMS, sizeof(uint2) * (n_items64 + 1), d_items.p);
     if (n_items64)
         hipLaunchKernelGGL(k_ovl_items, dim3((uint32_t)((n_items64 + 255) / 256)), dim3(256), 0, ctx->stream, d_ipre.as<uint32_t>(),
-                           d_off.as<uint32_t>(), nt, (uint32_t)n_items64, d_items.as<uint2>());
+                           d_woff, nt, (uint32_t)n_items64, d_items.as<uint2>());
     HIPCHK(hipStreamSynchronize(ctx->stream));                   // h_ipre must outlive its copy
     // one launch of the walk: items [lo, hi) of the group list (redo_in == nullptr) or n_redo parked runs
     auto walk = [&](int nb, const uint2 *items, uint32_t n_items, int full_band, const uint2 *redo_in) -> int {
@@ -414,7 +496,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     });
     *n_out = h_cnt2[0];
     st.n_overlaps = h_cnt2[0];
-    st.n_pairs = h_cnt2[1];
+    st.n_pairs = h_cnt2[1] + n_dropped;
     (void)hipEventElapsedTime(&st.scan_ms, ctx->ev[2], ctx->ev[3]);
     (void)hipEventElapsedTime(&st.sort_ms, ctx->ev[3], ctx->ev[4]);
     (void)hipEventElapsedTime(&st.walk_ms, ctx->ev[4], ctx->ev[5]);

@@ -23,6 +23,19 @@
 // scratch load per column of the sweep).
 struct PreThresholds {
     uint32_t p[(PBA_PRE_ROWS + 4) / 4];
+    PreThresholds() = default;
+    // formed on the host for a kernel that would otherwise form them once per thread (same FP64 products: -ffp-contract=off)
+    static PreThresholds on_host(double R) {
+        PreThresholds t;
+        for (int w = 0; w < (PBA_PRE_ROWS + 4) / 4; ++w) {
+            t.p[w] = 0;
+            for (int b = 0; b < 4; ++b) {
+                const int i = 4 * w + b;
+                if (i <= PBA_PRE_ROWS) t.p[w] |= (uint32_t)(int)__builtin_floor((double)i * R) << (8 * b);
+            }
+        }
+        return t;
+    }
     __device__ __forceinline__ explicit PreThresholds(double R) {
 #pragma unroll
         for (int w = 0; w < (PBA_PRE_ROWS + 4) / 4; ++w) {

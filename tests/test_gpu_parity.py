@@ -573,9 +573,19 @@ def test_locate_ecoli_scale_genome_vs_oracle(ctx, oracle):
     assert wst["n_located"] > 250 and wst["n_pairs"] > wst["n_located"]
 
 
+@pytest.fixture(params=["sorted_whole", "prefiltered_before_the_sort"])
+def prekeep(request, monkeypatch):
+    """The all-vs-all tests run twice: as small calls run by default (every candidate is sorted and walked), and with the stage
+    big calls get (>= 2^22 candidates) forced on -- the first prefilter stage before the sort, runs without a survivor
+    counted and dropped (overlap.h: k_ovl_pre / k_ovl_keep).  Same overlaps, same pair counts, both against the oracle."""
+    if request.param == "prefiltered_before_the_sort":
+        monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
+    return request.param == "prefiltered_before_the_sort"
+
+
 # ----------------------------------------------------------------------------- all-vs-all overlap
 @pytest.mark.parametrize("kernel", KERNELS)
-def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
+def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel, prekeep):
     """pba_overlap_all == running the oracle's locked spaced_seed round once per target read (every read in
     the reference role, every other read a query, intended seed_at): same successful (target, query) set, same
     j / dir / hit position / cost / match lengths, for whole ranges and for target shards."""
@@ -588,9 +598,10 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     file = b"".join(eng.text2bin(t) for t in texts)
     rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
     mask = eng.mask_from_pattern(MASK_PAT)
-    want = []
+    want, pairs = [], 0
     for t in range(n):
         rows = oracle.spaced_round(texts[t], mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=8)
+        pairs += int(rows["n_pairs"].sum()) - int(rows["n_pairs"][t])
         for q in range(n):
             if q != t and rows["found"][q]:
                 want.append((t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]),
@@ -599,7 +610,8 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel):
     S = ctx.seqs_from_list(texts, strict_acgt=True)
     got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=kernel)
     assert [tuple(int(x) for x in r) for r in got] == want
-    assert st["n_overlaps"] == len(want) and st["n_pairs"] >= len(want) and st["n_candidates"] >= st["n_pairs"]
+    assert st["n_overlaps"] == len(want) and st["n_pairs"] == pairs and st["n_candidates"] >= st["n_pairs"]
+    assert (st["n_prefiltered"] > 0) == (prekeep and kernel != PBA_KERNEL_ROWSWEEP)
     # target shards (what ranks of a multi-GPU run do) concatenate to the same answer
     parts = [ctx.overlap_all(S, mask, 0.30, 32, 64, t_lo=a, t_hi=b, kernel=kernel)[0] for a, b in ((0, 20), (20, 21), (21, 64))]
     assert [tuple(int(x) for x in r) for p in parts for r in p] == want
@@ -783,7 +795,7 @@ def test_locate_baseline_config1_shape_256_reads_vs_oracle(ctx, oracle):
     assert (rows["diag_cost"][rows["found"] == 1] >= rows["cost"][rows["found"] == 1]).all()
 
 
-def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):
+def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle, prekeep):
     """6.5 kb reads at ~12 % error each overlap at ~24 % between them: the first-pass window (1 384 in a one-block ring)
     cannot certify the longest true overlaps, the (target, query) run is parked and resumed at the reference band by
     the second launch -- and the answer is still the oracle's composition, with the number of pairs aligned equal to
@@ -810,7 +822,7 @@ def test_overlap_all_parks_and_resumes_uncertified_runs(ctx, oracle):
     assert st["n_pairs"] == pairs
 
 
-def test_overlap_all_cascade_through_the_middle_ring(ctx, oracle, monkeypatch):
+def test_overlap_all_cascade_through_the_middle_ring(ctx, oracle, monkeypatch, prekeep):
     """14 kb reads at 15 % error each (~27 % between two of them): max_dst = 4 201 puts the narrow window in a two-block
     ring (window 2 729) and the reference band in a four-block one, so the runs the first stage parks are resumed in
     the three-block ring (window 4 072: all the room it has) and only what that cannot certify goes on to the reference
@@ -1142,7 +1154,7 @@ def test_cons_vote_pairs_equals_scripts_then_elect(ctx):
     assert e.value.status == -1
 
 
-def test_overlap_all_with_tandem_repeats(ctx, oracle):
+def test_overlap_all_with_tandem_repeats(ctx, oracle, prekeep):
     """Reads that share a tandem repeat: one probe hits hundreds of positions of every other read, so a (target, query)
     run is thousands of candidates long -- it spans many 64-candidate work items (the owner rule), a target's list
     outgrows the LDS sort, and the first success sits deep inside a run.  Same answer as the oracle's composition."""
