@@ -373,6 +373,7 @@ struct OvlCfg {
     int overlap_min;
     int row_cap;      // u16 cells of LDS per wavefront
     uint32_t t2;
+    uint32_t chunk;   // work items a wavefront of the walk takes at a time when there are >= 2^20 of them (0: PBA_OVL_CHUNK)
 };
 
 // One candidate of target `ref` (length ref_len, visiting order ht) set up like spaced_seed.cpp:274-286 /
@@ -424,7 +425,8 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
 // and therefore still in the reference's order once sorted, plus a few per cent of false positives -- and the rest, runs
 // in which every candidate failed its first 32 rows, are pairs the reference aligned and dropped: counted, not sorted, not
 // walked.  Sort and walk then see ~3-5 % of the list and do with it exactly what they did with all of it.
-// Candidates the walk would skip before the aligner (OvlCand::ok false) are blanked here.
+// Candidates the walk would skip before the aligner (OvlCand::ok false) leave the list here (counted per target: they are
+// neither pairs nor kept).
 #define PBA_OVL_BLOOM_BITS 15
 #define PBA_OVL_BLOOM_WORDS (1u << (PBA_OVL_BLOOM_BITS - 5))
 __device__ __forceinline__ uint32_t ovl_bloom_slot(uint32_t q) { return (q * 0x9E3779B1u) >> (32 - PBA_OVL_BLOOM_BITS); }
@@ -456,8 +458,8 @@ k_ovl_ends(SeqSetDev Rd, uint32_t n, OvlEnd *ends) {
 
 // one wavefront per item = (target, 64 consecutive slots of its unsorted slice; cand_off[t + 1] ends the slice)
 static __global__ void __launch_bounds__(256)
-k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, uint64_t *cand, OvlCfg cfg,
-          PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, uint32_t *n_blanked) {
+k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
+          PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, uint32_t *n_blanked, uint16_t *slot_of) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
@@ -471,8 +473,7 @@ k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, con
     const bool bwd = (cdv >> PBA_OVL_ORD_BITS) & 1ull;
     const OvlEnd er = ends[2 * (size_t)(uint32_t)(cdv >> PBA_OVL_Q_SHIFT) + (bwd ? 1 : 0)];
     const OvlCand m = ovl_decode_len((int)er.len, ref_len, ht, cdv, cfg);
-    const bool blank = have && !m.ok;
-    if (blank) cand[c] = ~0ull;
+    const bool blank = have && !m.ok;                 // (leaves the list through its slot: 0xFFFF below)
     const uint64_t bm = __builtin_amdgcn_ballot_w64(blank);
     if (bm) atomicAdd(&n_blanked[it.x], lane == 0 ? (uint32_t)__builtin_popcountll(bm) : 0u);
     AlnOut po;
@@ -488,44 +489,42 @@ k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, con
         } else load_planes32(fetch_of(Rd, m.q, m.s_off, m.fwd ? 1 : -1), 0, blo, bhi);
         fr = prefilter32_planes(alo, ahi, blo, bhi, pre_t);
     }
-    if (have && m.ok && fr == 0) {
-        const uint32_t s = ovl_bloom_slot(m.q);
-        atomicOr(&bloom[(size_t)it.x * PBA_OVL_BLOOM_WORDS + (s >> 5)], 1u << (s & 31u));
-    }
+    // the Bloom slot of every candidate still in the list (0xFFFF: none), so that the passes that pack the list read 2 bytes
+    // per candidate instead of 8
+    const uint32_t s = ovl_bloom_slot(m.q);
+    if (c < cand_off[it.x + 1]) slot_of[c] = have && m.ok ? (uint16_t)s : (uint16_t)0xFFFFu;
+    if (have && m.ok && fr == 0) atomicOr(&bloom[(size_t)it.x * PBA_OVL_BLOOM_WORDS + (s >> 5)], 1u << (s & 31u));
 }
 
 // same items: the candidates whose query has its bit set are packed densely, target after target, into a second buffer (in
 // any order inside a target: they are sorted next).  Count per item, prefix sums over the items (k_scan_*), write -- a
 // cursor per target moved with atomics instead had every wavefront of the chip on the same few words (the items of a
 // target run together): 84 s of a 7.9 s run at a million reads.
-__device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, uint32_t tl, uint64_t cd) {
-    if (cd == ~0ull) return false;
-    const uint32_t s = ovl_bloom_slot((uint32_t)(cd >> PBA_OVL_Q_SHIFT));
-    return (bloom[(size_t)tl * PBA_OVL_BLOOM_WORDS + (s >> 5)] >> (s & 31u)) & 1u;
+__device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, uint32_t tl, uint32_t s) {
+    return s != 0xFFFFu && ((bloom[(size_t)tl * PBA_OVL_BLOOM_WORDS + (s >> 5)] >> (s & 31u)) & 1u);
 }
 // kept_of[item] = candidates of the item that stay
 static __global__ void __launch_bounds__(256)
-k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint32_t *bloom,
+k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint16_t *slot_of, const uint32_t *bloom,
                  uint32_t *kept_of) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, it.x, c < cand_off[it.x + 1] ? cand[c] : ~0ull));
+    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu));
     if (lane == 0) kept_of[item] = (uint32_t)__builtin_popcountll(km);
 }
 // kept_before[item] = candidates kept by the items before it (kept_before[n_items] = all of them)
 static __global__ void __launch_bounds__(256)
-k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint32_t *bloom,
-                 const uint32_t *kept_before, uint64_t *kept) {
+k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint16_t *slot_of,
+                 const uint32_t *bloom, const uint32_t *kept_before, uint64_t *kept) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const uint64_t cd = c < cand_off[it.x + 1] ? cand[c] : ~0ull;
-    const bool keep = ovl_kept(bloom, it.x, cd);
+    const bool keep = ovl_kept(bloom, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu);
     const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
-    if (keep) kept[kept_before[item] + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = cd;
+    if (keep) kept[kept_before[item] + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = cand[c];
 }
 // where every target's kept candidates start in the packed list: the prefix sum at its first item
 static __global__ void __launch_bounds__(256)
@@ -560,7 +559,9 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
     // addresses).  Items are taken up to 16 at a time and the pairs are added up per wavefront.
     // (below a million items chunks cost more in load balance at the end of the launch than they save: an item with a true
     // overlap is ~500 x a group of false candidates)
-    const uint32_t chunk = (redo_in || n_items < (1u << 20)) ? 1u : (uint32_t)PBA_OVL_CHUNK;
+    // (after the pre-sort prefilter stage an item is 64 candidates of runs that hold a survivor -- a true overlap in every
+    // fourth: the host then asks for single items, cfg.chunk = 1)
+    const uint32_t chunk = (redo_in || n_items < (1u << 20)) ? 1u : (cfg.chunk ? min(cfg.chunk, (uint32_t)PBA_OVL_CHUNK) : (uint32_t)PBA_OVL_CHUNK);
     // Two-stage prefilter over a chunk (first launch, bit-vector kernels): the first 32 rows of every candidate of the
     // chunk's groups (one candidate per lane, prefilter32), the survivors of ALL its groups listed in LDS and put
     // through rows 33..64 together (prefilter64, one survivor per lane) -- and only what passes both reaches the

@@ -243,7 +243,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     if (const char *e = getenv("PBA_OVL_PREKEEP_MIN")) prekeep_min = (uint64_t)std::max(0LL, atoll(e));   // test hook: small inputs through the stage (or none)
     const bool prekeep = pl.nb1 != 0 && total >= prekeep_min && total > 0;
     OvlCfg ocfg;
-    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2;
+    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2; ocfg.chunk = prekeep ? 1u : 0u;
     std::vector<uint32_t> h_kept, h_koff;                        // per target: candidates kept, and where they start in the packed list
     uint32_t *d_koff = nullptr;
     uint64_t n_dropped = 0;
@@ -265,26 +265,27 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         BufRef d_bloom;
         const size_t bloom_words = (size_t)nt * PBA_OVL_BLOOM_WORDS;
         const uint32_t n_tiles = (uint32_t)((n_it + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
-        POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles), d_bloom.p);
+        POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles) + sizeof(uint16_t) * (total + 2), d_bloom.p);
         HIPCHK(hipMemsetAsync(d_bloom.p, 0, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + 1), ctx->stream));
         uint32_t *const d_blanked = d_bloom.as<uint32_t>() + bloom_words;
         d_koff = d_blanked + (nt + 1);
         uint32_t *const d_before = d_koff + (nt + 1);            // [n_it + 1], [0] = 0 (the memset above reaches it)
         uint32_t *const d_tiles = d_before + n_it + 1;
+        uint16_t *const d_slot = (uint16_t *)(d_tiles + n_tiles);    // [total]: the Bloom slot of every candidate
         POOL(POOL_OVL_TMP, sizeof(uint64_t) * (total + 1), d_tmp.p);
         BufRef d_ends;                                           // the ends of every read side by side (overlap.h: OvlEnd)
         POOL(POOL_OVL_ENDS, sizeof(OvlEnd) * 2 * (size_t)n, d_ends.p);
         hipLaunchKernelGGL(k_ovl_ends, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reads->dev(), n, d_ends.as<OvlEnd>());
         const uint32_t g = (uint32_t)((n_it + 3) / 4);
         hipLaunchKernelGGL(k_ovl_pre, dim3(g), dim3(256), 0, ctx->stream, reads->dev(), t_lo, (uint32_t)n_it, d_items.as<uint2>(),
-                           d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), d_blanked);
+                           d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), d_blanked, d_slot);
         hipLaunchKernelGGL(k_ovl_keep_count, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
-                           d_cand.as<uint64_t>(), d_bloom.as<uint32_t>(), d_before + 1);
+                           d_slot, d_bloom.as<uint32_t>(), d_before + 1);
         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
         hipLaunchKernelGGL(k_ovl_keep_write, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
-                           d_cand.as<uint64_t>(), d_bloom.as<uint32_t>(), d_before, d_tmp.as<uint64_t>());
+                           d_cand.as<uint64_t>(), d_slot, d_bloom.as<uint32_t>(), d_before, d_tmp.as<uint64_t>());
         hipLaunchKernelGGL(k_ovl_keep_offsets, dim3((nt + 256) / 256), dim3(256), 0, ctx->stream, d_ipre1, d_before, nt, d_koff);
         h_koff.resize(nt + 1);
         std::vector<uint32_t> h_blanked(nt + 1);

@@ -12,6 +12,7 @@ ap.add_argument("--read-len", type=int, default=15000)
 ap.add_argument("--coverage", type=float, default=20.0)
 ap.add_argument("--R", type=float, default=0.30)
 ap.add_argument("--trials", type=int, default=32)
+ap.add_argument("--reps", type=int, default=1, help="timed passes; the fastest is reported")
 ap.add_argument("--targets-per-call", type=int, default=0, help="> 0: go through the targets in ranges (one probe table)")
 a = ap.parse_args()
 L = int(a.reads * a.read_len / a.coverage)
@@ -22,19 +23,24 @@ S = ctx.seqs_from_text(reads, offs, strict_acgt=True)
 mask = eng.mask_from_pattern("111*11*11*1*1111")
 cap = a.reads * 400
 ctx.overlap_all(S, mask, a.R, a.trials, 64, t_lo=0, t_hi=min(64, a.reads), cap=cap)       # warm-up
-t = time.perf_counter()
-if a.targets_per_call > 0:
-    ov, st = ctx.overlap_all_sharded(S, mask, a.R, a.trials, 64, targets_per_call=a.targets_per_call, cap_per_target=400)
-else:
-    ov, st = ctx.overlap_all(S, mask, a.R, a.trials, 64, cap=cap)
-dt = time.perf_counter() - t
+best = None
+for rep in range(max(1, a.reps)):              # (the first pass of a process also sizes the ctx's work buffers: tens of GB of hipMalloc)
+    t = time.perf_counter()
+    if a.targets_per_call > 0:
+        ov, st = ctx.overlap_all_sharded(S, mask, a.R, a.trials, 64, targets_per_call=a.targets_per_call, cap_per_target=400)
+    else:
+        ov, st = ctx.overlap_all(S, mask, a.R, a.trials, 64, cap=cap)
+    dt = time.perf_counter() - t
+    if best is None or dt < best[0]:
+        best = (dt, st)
+dt, st = best
 # scan roofline: algorithmic bytes = 0.25 B per visited position (the packed bases, read once) + 8 B per
 # candidate written; the scan makes two passes over the positions (slice sizes, then the candidates)
 visited = sum(min(a.read_len - 16, 20000) + max(0, min(a.read_len - 20016, 20000)) for _ in range(1)) * a.reads
 scan_bytes = visited * 0.25 + st["n_candidates"] * 8
 scan_gbs = scan_bytes / (st["scan_ms"] * 1e-3) / 1e9 if st["scan_ms"] > 0 else 0.0
 print(json.dumps({"workload": f"all-vs-all, {a.reads} x {a.read_len} reads @15%, genome {L} ({a.coverage}x), R={a.R}, {a.trials} trials/end",
-                  "seconds": round(dt, 3), "overlaps": int(st["n_overlaps"]), "pairs": int(st["n_pairs"]),
+                  "seconds": round(dt, 3), "reps": a.reps, "n_prefiltered": int(st.get("n_prefiltered", 0)), "overlaps": int(st["n_overlaps"]), "pairs": int(st["n_pairs"]),
                   "candidates": int(st["n_candidates"]), "pairs_per_s": round(st["n_pairs"] / dt, 1),
                   "overlaps_per_s": round(st["n_overlaps"] / dt, 1), "table_ms": st["table_ms"], "scan_ms": st["scan_ms"],
                   "sort_ms": st["sort_ms"], "walk_ms": st["walk_ms"], "n_big_targets": st.get("n_big_targets", 0),
