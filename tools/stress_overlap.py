@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Differential stress of the all-vs-all path: the bit-vector walk with everything round 2 put around it (pre-sort prefilter
+stage forced on and off, early give-up of narrow passes, parked runs through the rings) against the row-sweep kernel,
+which has no windows, no prefilter and no certificates -- same overlaps row by row, same pair counts.  Random read sets:
+lengths from below the 500-base cut to 16 kb, per-read error from 1 % to 17 %, indel-heavy and substitution-heavy mixes,
+coverage 4x-30x.  Prints one line per round; exits 1 on the first disagreement."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pacbioassembly_amd import Context, engine as eng
+from pacbioassembly_amd.engine import PBA_KERNEL_BITVEC, PBA_KERNEL_ROWSWEEP
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=6)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--max-len", type=int, default=16000)
+a = ap.parse_args()
+ctx = Context(0)
+rng = np.random.RandomState(a.seed)
+masks = ["111*11*11*1*1111", "1111**1111**1111", "11*11*11*11*1111"]
+bad = 0
+for rnd in range(a.rounds):
+    rl = int(rng.choice([700, 1500, 3000, 6500, 10000, a.max_len]))
+    n = int(rng.randint(24, 120)) if rl <= 3000 else int(rng.randint(16, 48))
+    if rl <= 1500 and rng.rand() < 0.5:
+        n = int(rng.randint(1500, 4000))                              # many short reads: false candidates by the hundred thousand
+    cov = float(rng.choice([4, 10, 20, 30]))
+    L = max(2 * rl, int(n * rl / cov))
+    e = float(rng.choice([0.01, 0.05, 0.10, 0.13, 0.15, 0.17]))
+    mix = rng.dirichlet([1, 1, 1]) * e
+    g = eng.synth_genome(1000 + a.seed * 100 + rnd, L)
+    reads, offs, _ = eng.synth_reads(2000 + a.seed * 100 + rnd, g, n, rl, float(mix[0]), float(mix[1]), float(mix[2]))
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+    for k in rng.choice(n, size=max(1, n // 8), replace=False):          # ragged: some reads cut short, one or two below the cut
+        texts[k] = texts[k][: int(rng.randint(60, max(61, rl)))]
+    S = ctx.seqs_from_list(texts, strict_acgt=True)
+    mask = eng.mask_from_pattern(masks[rnd % len(masks)])
+    R = float(rng.choice([0.15, 0.25, 0.30, 0.35]))
+    trials = int(rng.choice([8, 32]))
+    os.environ.pop("PBA_OVL_PREKEEP_MIN", None)
+    want, wst = ctx.overlap_all(S, mask, R, trials, 64, kernel=PBA_KERNEL_ROWSWEEP)
+    line = f"round {rnd}: {n} reads x {rl} @ {e:.2f} ({mix[0]:.3f}/{mix[1]:.3f}/{mix[2]:.3f}) cov {cov:.0f} R {R} trials {trials}: " \
+           f"{len(want)} overlaps, {wst['n_pairs']} pairs, {wst['n_candidates']} candidates"
+    for mode in ("0", "1000000000000"):
+        os.environ["PBA_OVL_PREKEEP_MIN"] = mode
+        got, st = ctx.overlap_all(S, mask, R, trials, 64, kernel=PBA_KERNEL_BITVEC)
+        ok = (got.size == want.size and (got == want).all() and st["n_pairs"] == wst["n_pairs"]
+              and st["n_candidates"] == wst["n_candidates"])
+        line += f" | prekeep {'on' if mode == '0' else 'off'}: {'same' if ok else 'DIFFERENT'} (redo {st['n_redo']}, prefiltered {st['n_prefiltered']})"
+        bad += not ok
+    print(line, flush=True)
+    S.close()
+    if bad:
+        sys.exit(1)
+print("all rounds agree")
