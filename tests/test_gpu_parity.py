@@ -1295,6 +1295,20 @@ def test_locate_random_configs_vs_oracle():
     assert r.stdout.count("same=True") == 4
 
 
+def test_overlap_random_read_sets_bitvec_forms_vs_rowsweep():
+    """tools/stress_overlap.py: all-vs-all on random read sets (60 ... 16 000 bases, 1-17 % error in indel- and substitution-
+    heavy mixes, R 0.15-0.35, up to 4 000 reads) -- the bit-vector walk, with the pre-sort prefilter stage forced on and
+    without it, gives the row-sweep kernel's overlaps row by row and its pair and candidate counts."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_overlap.py"), "--rounds", "5", "--seed", str(7 + SOAK)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("same") == 10 and "DIFFERENT" not in r.stdout and "all rounds agree" in r.stdout
+
+
 def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
     """The N > 1 paths of bench.py on the GPU box there is: two ranks (started by bench.py's own launcher) share the one GPU
     and exchange over gloo instead of RCCL (which needs a GPU per rank) -- seed-index exchange and locate in weak scaling,
