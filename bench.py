@@ -324,7 +324,20 @@ def run_rank(a):
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.exchange
     if use_dist:
-        os.environ["NCCL_DEBUG"] = os.environ.get("PBA_NCCL_DEBUG", "WARN")   # no RCCL banner on stdout: ONE JSON line
+        # RCCL writes its log to STDOUT (version banner, warnings about the host's kernel command line, ...), which must carry
+        # ONE JSON line: the log goes to a file per process and is relayed to stderr when the process ends
+        os.environ["NCCL_DEBUG"] = os.environ.get("PBA_NCCL_DEBUG", "WARN")
+        rccl_log = os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/pba_rccl_{os.getpid()}.log")
+
+        def relay_rccl_log():
+            try:
+                with open(rccl_log) as f:
+                    sys.stderr.write(f.read())
+                os.remove(rccl_log)
+            except OSError:
+                pass
+        import atexit
+        atexit.register(relay_rccl_log)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if a.backend == "nccl":
