@@ -420,16 +420,21 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
 // 98.6 % of the candidates fail their first 32 rows (prefilter.h), and all a failed candidate ever contributes is +1 to the
 // pair count -- unless its (target, query) run has a success before it, in which case the reference never tried it.  A run
 // with a success has a candidate that passes the prefilter.  So: k_ovl_pre runs the first stage over the UNSORTED slices
-// and sets, per target, a bit for the query of every candidate that passes (a Bloom filter with one hash: 2^15 bits per
-// target); k_ovl_keep then keeps the candidates whose query has its bit set -- every run that can hold a success, whole
+// and sets, per target, a bit for the query of every candidate that passes (a Bloom filter with one hash: 2^10 .. 2^16 bits
+// per target); k_ovl_keep then keeps the candidates whose query has its bit set -- every run that can hold a success, whole
 // and therefore still in the reference's order once sorted, plus a few per cent of false positives -- and the rest, runs
 // in which every candidate failed its first 32 rows, are pairs the reference aligned and dropped: counted, not sorted, not
 // walked.  Sort and walk then see ~3-5 % of the list and do with it exactly what they did with all of it.
 // Candidates the walk would skip before the aligner (OvlCand::ok false) leave the list here (counted per target: they are
 // neither pairs nor kept).
-#define PBA_OVL_BLOOM_BITS 15
-#define PBA_OVL_BLOOM_WORDS (1u << (PBA_OVL_BLOOM_BITS - 5))
-__device__ __forceinline__ uint32_t ovl_bloom_slot(uint32_t q) { return (q * 0x9E3779B1u) >> (32 - PBA_OVL_BLOOM_BITS); }
+// bits per target: a power of two, about twice the candidates a target has on average (a thirtieth of them set a bit),
+// between 2^10 and 2^16 (a slot fits the 2-byte array of the packing passes; 0xFFFF = none)
+#define PBA_OVL_BLOOM_MIN_BITS 10
+#define PBA_OVL_BLOOM_MAX_BITS 16
+__device__ __forceinline__ uint32_t ovl_bloom_slot(uint32_t q, int bits) {
+    const uint32_t s = (q * 0x9E3779B1u) >> (32 - bits);
+    return s == 0xFFFFu ? 0xFFFEu : s;
+}
 
 // What the stage needs of a QUERY is its length and 32 bases next to one of its ends (a probe sits at offset j <= 31 from
 // the start, or from the end walking left): through the read set that is three scattered lines per candidate (length,
@@ -459,7 +464,7 @@ k_ovl_ends(SeqSetDev Rd, uint32_t n, OvlEnd *ends) {
 // one wavefront per item = (target, 64 consecutive slots of its unsorted slice; cand_off[t + 1] ends the slice)
 static __global__ void __launch_bounds__(256)
 k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
-          PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, uint32_t *n_blanked, uint16_t *slot_of) {
+          PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, int bloom_bits, uint32_t *n_blanked, uint16_t *slot_of) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
@@ -491,38 +496,38 @@ k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, con
     }
     // the Bloom slot of every candidate still in the list (0xFFFF: none), so that the passes that pack the list read 2 bytes
     // per candidate instead of 8
-    const uint32_t s = ovl_bloom_slot(m.q);
+    const uint32_t s = ovl_bloom_slot(m.q, bloom_bits);
     if (c < cand_off[it.x + 1]) slot_of[c] = have && m.ok ? (uint16_t)s : (uint16_t)0xFFFFu;
-    if (have && m.ok && fr == 0) atomicOr(&bloom[(size_t)it.x * PBA_OVL_BLOOM_WORDS + (s >> 5)], 1u << (s & 31u));
+    if (have && m.ok && fr == 0) atomicOr(&bloom[((size_t)it.x << (bloom_bits - 5)) + (s >> 5)], 1u << (s & 31u));
 }
 
 // same items: the candidates whose query has its bit set are packed densely, target after target, into a second buffer (in
 // any order inside a target: they are sorted next).  Count per item, prefix sums over the items (k_scan_*), write -- a
 // cursor per target moved with atomics instead had every wavefront of the chip on the same few words (the items of a
 // target run together): 84 s of a 7.9 s run at a million reads.
-__device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, uint32_t tl, uint32_t s) {
-    return s != 0xFFFFu && ((bloom[(size_t)tl * PBA_OVL_BLOOM_WORDS + (s >> 5)] >> (s & 31u)) & 1u);
+__device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, int bloom_bits, uint32_t tl, uint32_t s) {
+    return s != 0xFFFFu && ((bloom[((size_t)tl << (bloom_bits - 5)) + (s >> 5)] >> (s & 31u)) & 1u);
 }
 // kept_of[item] = candidates of the item that stay
 static __global__ void __launch_bounds__(256)
 k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint16_t *slot_of, const uint32_t *bloom,
-                 uint32_t *kept_of) {
+                 int bloom_bits, uint32_t *kept_of) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu));
+    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, bloom_bits, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu));
     if (lane == 0) kept_of[item] = (uint32_t)__builtin_popcountll(km);
 }
 // kept_before[item] = candidates kept by the items before it (kept_before[n_items] = all of them)
 static __global__ void __launch_bounds__(256)
 k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint16_t *slot_of,
-                 const uint32_t *bloom, const uint32_t *kept_before, uint64_t *kept) {
+                 const uint32_t *bloom, int bloom_bits, const uint32_t *kept_before, uint64_t *kept) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const bool keep = ovl_kept(bloom, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu);
+    const bool keep = ovl_kept(bloom, bloom_bits, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu);
     const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
     if (keep) kept[kept_before[item] + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = cand[c];
 }

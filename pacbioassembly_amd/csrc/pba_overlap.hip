@@ -236,10 +236,13 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     }
     (void)hipEventRecord(ctx->ev[3], ctx->stream);
 
-    // 2b. big calls on the bit-vector kernels: the first prefilter stage before the sort (overlap.h: k_ovl_pre / k_ovl_keep).
+    // 2b. big calls (>= 2^29 candidates) on the bit-vector kernels: the first prefilter stage before the sort (overlap.h: k_ovl_pre / k_ovl_keep).
     //     What is kept goes packed into the second buffer; the sort below moves it back, sorted; everything after sees the
     //     packed list (h_koff / h_kept) where it saw the slices (h_off / h_valid).  The time is the sort's in the statistics.
-    uint64_t prekeep_min = 1ull << 22;
+    // (measured, calls of 50 000 targets: 23 M candidates 0.081 s with the stage / 0.065 s without -- the few thousand dense
+    // items that are left balance badly over 8 192 wavefronts --, 143 M 0.157 / 0.151, 573 M 0.333 / 0.330, 2.3 G 0.718 / 0.743,
+    // 9.2 G 1.68 / 1.99, 57 G 5.8 / 7.9)
+    uint64_t prekeep_min = 1ull << 29;
     if (const char *e = getenv("PBA_OVL_PREKEEP_MIN")) prekeep_min = (uint64_t)std::max(0LL, atoll(e));   // test hook: small inputs through the stage (or none)
     const bool prekeep = pl.nb1 != 0 && total >= prekeep_min && total > 0;
     OvlCfg ocfg;
@@ -263,7 +266,9 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         // per target: the Bloom words, its blanked count; per item: the kept counts (+1: exclusive prefix sums); per target + 1:
         // the offsets into the packed list
         BufRef d_bloom;
-        const size_t bloom_words = (size_t)nt * PBA_OVL_BLOOM_WORDS;
+        int bloom_bits = PBA_OVL_BLOOM_MIN_BITS;                 // ~2 x the average candidates of a target, a power of two
+        while (bloom_bits < PBA_OVL_BLOOM_MAX_BITS && (1ull << bloom_bits) < 2 * (total / nt)) ++bloom_bits;
+        const size_t bloom_words = (size_t)nt << (bloom_bits - 5);
         const uint32_t n_tiles = (uint32_t)((n_it + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
         POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles) + sizeof(uint16_t) * (total + 2), d_bloom.p);
         HIPCHK(hipMemsetAsync(d_bloom.p, 0, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + 1), ctx->stream));
@@ -278,14 +283,14 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         hipLaunchKernelGGL(k_ovl_ends, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reads->dev(), n, d_ends.as<OvlEnd>());
         const uint32_t g = (uint32_t)((n_it + 3) / 4);
         hipLaunchKernelGGL(k_ovl_pre, dim3(g), dim3(256), 0, ctx->stream, reads->dev(), t_lo, (uint32_t)n_it, d_items.as<uint2>(),
-                           d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), d_blanked, d_slot);
+                           d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), bloom_bits, d_blanked, d_slot);
         hipLaunchKernelGGL(k_ovl_keep_count, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
-                           d_slot, d_bloom.as<uint32_t>(), d_before + 1);
+                           d_slot, d_bloom.as<uint32_t>(), bloom_bits, d_before + 1);
         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
         hipLaunchKernelGGL(k_ovl_keep_write, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
-                           d_cand.as<uint64_t>(), d_slot, d_bloom.as<uint32_t>(), d_before, d_tmp.as<uint64_t>());
+                           d_cand.as<uint64_t>(), d_slot, d_bloom.as<uint32_t>(), bloom_bits, d_before, d_tmp.as<uint64_t>());
         hipLaunchKernelGGL(k_ovl_keep_offsets, dim3((nt + 256) / 256), dim3(256), 0, ctx->stream, d_ipre1, d_before, nt, d_koff);
         h_koff.resize(nt + 1);
         std::vector<uint32_t> h_blanked(nt + 1);

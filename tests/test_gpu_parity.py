@@ -576,7 +576,7 @@ def test_locate_ecoli_scale_genome_vs_oracle(ctx, oracle):
 @pytest.fixture(params=["sorted_whole", "prefiltered_before_the_sort"])
 def prekeep(request, monkeypatch):
     """The all-vs-all tests run twice: as small calls run by default (every candidate is sorted and walked), and with the stage
-    big calls get (>= 2^22 candidates) forced on -- the first prefilter stage before the sort, runs without a survivor
+    big calls get (>= 2^29 candidates) forced on -- the first prefilter stage before the sort, runs without a survivor
     counted and dropped (overlap.h: k_ovl_pre / k_ovl_keep).  Same overlaps, same pair counts, both against the oracle."""
     if request.param == "prefiltered_before_the_sort":
         monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
