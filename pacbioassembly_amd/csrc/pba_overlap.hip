@@ -33,6 +33,11 @@ struct pba_probe_table {
     uint32_t t2;
     uint64_t n_entries;
     float build_ms;
+    // what a call learned from its sample about this read set under (R, ring): whether the narrow window certifies its
+    // overlaps.  The next target ranges against the same table skip the sample (three launches and their tails per call).
+    mutable int wide_known;        // -1: not sampled yet, 0: start narrow, 1: start in the middle ring / at the reference band
+    mutable double wide_R;
+    mutable int wide_nb1;
 };
 
 int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint32_t q_hi, uint32_t mask, int max_trial,
@@ -113,7 +118,7 @@ int pba_probe_table_create(pba_ctx *ctx, const void *d_probe_entries, uint64_t n
     pba_probe_table *t = new (std::nothrow) pba_probe_table();
     if (!t) PBA_FAIL(PBA_E_NOMEM, "pba_probe_table");
     memset(t, 0, sizeof *t);
-    t->device = ctx->device; t->t2 = 2u * (uint32_t)max_trial;
+    t->device = ctx->device; t->t2 = 2u * (uint32_t)max_trial; t->wide_known = -1;
     struct Guard { pba_probe_table *p; ~Guard() { pba_probe_table_destroy(p); } } guard{t};
     const int care = __builtin_popcount(mask);
     t->hashed = care > PBA_PT_MAX_BITS;
@@ -467,16 +472,22 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     const size_t n_all = (size_t)n_items64;
     size_t sample_min = 4096;
     if (const char *e = getenv("PBA_OVL_SAMPLE_MIN")) sample_min = (size_t)std::max(1L, atol(e));   // test hook: small inputs through the sampled decision
-    const size_t n_sample = pl.nb1 == 0 ? n_all : std::min(n_all, std::max<size_t>(sample_min, n_all / 32));
+    const bool decided = tab->wide_known >= 0 && tab->wide_R == R && tab->wide_nb1 == pl.nb1 && !getenv("PBA_OVL_SAMPLE_MIN");
+    const size_t n_sample = pl.nb1 == 0 ? n_all : (decided ? 0 : std::min(n_all, std::max<size_t>(sample_min, n_all / 32)));
     uint64_t parked = 0;
     rc = narrow_then_redo(pl.nb1, 0, n_sample, &parked);
     if (rc != PBA_OK) return rc;
     parked_total += parked;
     if (n_sample < n_all) {
         unsigned long long h_ov = 0;
-        HIPCHK(hipMemcpyAsync(&h_ov, d_cnt64.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (2 * parked > h_ov) {                                 // most overlaps of the sample needed more than the narrow window
+        if (!decided) {
+            HIPCHK(hipMemcpyAsync(&h_ov, d_cnt64.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (n_sample >= 4096) {                              // a sample worth remembering
+                tab->wide_known = 2 * parked > h_ov ? 1 : 0; tab->wide_R = R; tab->wide_nb1 = pl.nb1;
+            }
+        }
+        if (decided ? tab->wide_known == 1 : 2 * parked > h_ov) {   // most overlaps of the sample needed more than the narrow window
             st.wide_first = 1;
             if (nb_mid) {
                 rc = narrow_then_redo(nb_mid, n_sample, n_all, &parked);
