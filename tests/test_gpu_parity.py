@@ -1309,6 +1309,19 @@ def test_overlap_random_read_sets_bitvec_forms_vs_rowsweep():
     assert r.stdout.count("same") == 10 and "DIFFERENT" not in r.stdout and "all rounds agree" in r.stdout
 
 
+def test_overlap_repeats_outgrow_one_sort_with_and_without_the_pre_sort_stage():
+    """tools/dbg_repeats.py: 160 reads over a genome with 2 kb of period-23 tandem repeat -- 7.4 M candidates, most of them
+    real matches, 142 targets whose lists outgrow one LDS sort (cut into pieces without the stage; packed lists beyond one
+    sort go through the global pass with it): the bit-vector walk gives the row-sweep kernel's rows and counts both ways."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_repeats.py"), "160"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" same ") == 2 and "big targets 142" in r.stdout
+
+
 def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
     """The N > 1 paths of bench.py on the GPU box there is: two ranks (started by bench.py's own launcher) share the one GPU
     and exchange over gloo instead of RCCL (which needs a GPU per rank) -- seed-index exchange and locate in weak scaling,
