@@ -217,8 +217,10 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
 
+    step(t_hi=min(r_hi, r_lo + 256))                       # a sliver of the targets first: kernels, RCCL
     for _ in range(max(warmup, 1)):
-        step(t_hi=min(r_hi, r_lo + 256))                   # warm-up on a sliver of the targets: allocator, kernels, RCCL
+        step()                                             # warm-up proper: a whole pass also sizes the ctx's work buffers
+                                                           # (tens of GB of hipMalloc: 0.1 s of a 0.8 s pass at 200 k reads)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
