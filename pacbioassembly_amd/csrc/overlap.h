@@ -14,9 +14,11 @@
 //   (per-target sort of the candidates in LDS; 64-bit order = query, then j, forward before backward, then the
 //    seedmap's list order -- exactly the order spaced_seed tries them in; big targets are cut into pieces of
 //    consecutive queries first: k_ovl_split, then k_seg_sort piece by piece)
+//   (calls with >= 2^29 candidates: k_ovl_ends / k_ovl_pre / k_ovl_keep_* first -- the first prefilter stage over the unsorted
+//    list, only the runs that can hold a success are sorted and walked, the rest are counted; further down)
 //   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query;
-//                  (target, query) runs whose narrow-window verdict is not certified are parked and resumed by a
-//                  second launch at the reference band
+//                  (target, query) runs whose narrow-window verdict is not certified (or whose narrow pass was given up: it
+//                  was heading past what the window certifies) are parked and resumed by later launches in wider rings
 #ifndef PBA_OVERLAP_H
 #define PBA_OVERLAP_H
 
