@@ -402,6 +402,8 @@ typedef struct {
     uint32_t n_big_targets;        /* targets whose candidates outgrew one LDS sort and were cut into pieces of consecutive queries */
     uint64_t n_prefiltered;        /* candidates of n_pairs that were dropped before the sort: every candidate of their (target, query)
                                       run failed the reference's diagonal check within its first 32 rows (big calls only, else 0) */
+    uint32_t cap_fill;             /* 1: the candidate slices were not counted first but given equal room, sized by an earlier range of the table */
+    uint32_t cap_overflow;         /* 1: a slice outgrew that room and the range was run again the counted way */
 } pba_overlap_stats;
 
 /* Limits of the all-vs-all entry points (explicit PBA_E_TOOLONG beyond them, never a wrapped count):

@@ -203,7 +203,11 @@ k_ovl_count(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_
 
 template <bool HASHED>
 static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
-k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, uint64_t *cand, uint32_t *valid) {
+k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, uint64_t *cand, uint32_t *valid,
+           uint32_t slice_cap, uint32_t *written) {
+    // slice_cap != 0: the slices were not counted first but given slice_cap slots each (the host's guess from an earlier
+    // range of the same table); nothing is stored beyond that, written[t] says how many slots the target needed -- more than
+    // slice_cap and the host runs the range again the counted way.
     __shared__ uint32_t r_s0[PBA_OVL_WAVES][PBA_OVL_RUNS];         // first entry of the run
     __shared__ uint32_t r_rel[PBA_OVL_WAVES][PBA_OVL_RUNS + 1];    // its first slot, relative to the step's reservation
     __shared__ uint16_t r_ord[PBA_OVL_WAVES][PBA_OVL_RUNS];        // ordinal of the position
@@ -279,7 +283,8 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
             const uint64_t lowbits = (uint64_t)r_ord[w][r];
             const uint32_t want = HASHED ? r_key[w][r] : 0u;
             uint64_t *o = out + base + rel;
-            for (uint32_t h = 0; h < cnt; ++h) {
+            const uint32_t room = slice_cap == 0 ? cnt : (base + rel >= slice_cap ? 0u : min(cnt, slice_cap - (base + rel)));
+            for (uint32_t h = 0; h < room; ++h) {
                 const uint32_t pe = h ? T.pid[e0 + h] : r_first[w][r];
                 const uint32_t q = pe >> PBA_OVL_JD_BITS;
                 bool ok = q != t;
@@ -296,7 +301,7 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
     for (int d = 1; d < PBA_WAVE; d <<= 1) myvalid += __shfl_xor(myvalid, d, PBA_WAVE);
     if (lane == 0 && myvalid) atomicAdd(&nvalid, myvalid);
     __syncthreads();
-    if (threadIdx.x == 0) valid[tl] = nvalid;
+    if (threadIdx.x == 0) { valid[tl] = nvalid; if (written) written[tl] = cursor; }
 }
 
 // A target whose slice outgrows one LDS sort (a million reads put 57 000 candidates on a target) is cut into pieces of
@@ -463,15 +468,15 @@ k_ovl_ends(SeqSetDev Rd, uint32_t n, OvlEnd *ends) {
     ends[2 * (size_t)q] = h; ends[2 * (size_t)q + 1] = t;
 }
 
-// one wavefront per item = (target, 64 consecutive slots of its unsorted slice; cand_off[t + 1] ends the slice)
+// one wavefront per item = (target, 64 consecutive slots of its unsorted slice; cand_end[t] ends the slice)
 static __global__ void __launch_bounds__(256)
-k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, OvlCfg cfg,
+k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_end, const uint64_t *cand, OvlCfg cfg,
           PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, int bloom_bits, uint32_t *n_blanked, uint16_t *slot_of) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const uint64_t cd = c < cand_off[it.x + 1] ? cand[c] : ~0ull;
+    const uint64_t cd = c < cand_end[it.x] ? cand[c] : ~0ull;
     const uint32_t t = t_lo + it.x;
     const int ref_len = (int)Rd.len[t];
     const HeadTail ht(ref_len);
@@ -499,7 +504,7 @@ k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, con
     // the Bloom slot of every candidate still in the list (0xFFFF: none), so that the passes that pack the list read 2 bytes
     // per candidate instead of 8
     const uint32_t s = ovl_bloom_slot(m.q, bloom_bits);
-    if (c < cand_off[it.x + 1]) slot_of[c] = have && m.ok ? (uint16_t)s : (uint16_t)0xFFFFu;
+    if (c < cand_end[it.x]) slot_of[c] = have && m.ok ? (uint16_t)s : (uint16_t)0xFFFFu;
     if (have && m.ok && fr == 0) atomicOr(&bloom[((size_t)it.x << (bloom_bits - 5)) + (s >> 5)], 1u << (s & 31u));
 }
 
@@ -512,24 +517,24 @@ __device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, int bloom_bits, 
 }
 // kept_of[item] = candidates of the item that stay
 static __global__ void __launch_bounds__(256)
-k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint16_t *slot_of, const uint32_t *bloom,
+k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_end, const uint16_t *slot_of, const uint32_t *bloom,
                  int bloom_bits, uint32_t *kept_of) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, bloom_bits, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu));
+    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, bloom_bits, it.x, c < cand_end[it.x] ? slot_of[c] : 0xFFFFu));
     if (lane == 0) kept_of[item] = (uint32_t)__builtin_popcountll(km);
 }
 // kept_before[item] = candidates kept by the items before it (kept_before[n_items] = all of them)
 static __global__ void __launch_bounds__(256)
-k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_off, const uint64_t *cand, const uint16_t *slot_of,
+k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_end, const uint64_t *cand, const uint16_t *slot_of,
                  const uint32_t *bloom, int bloom_bits, const uint32_t *kept_before, uint64_t *kept) {
     const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
     if (item >= n_items) return;
     const uint2 it = items[item];
     const uint32_t c = it.y + lane;
-    const bool keep = ovl_kept(bloom, bloom_bits, it.x, c < cand_off[it.x + 1] ? slot_of[c] : 0xFFFFu);
+    const bool keep = ovl_kept(bloom, bloom_bits, it.x, c < cand_end[it.x] ? slot_of[c] : 0xFFFFu);
     const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
     if (keep) kept[kept_before[item] + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = cand[c];
 }

@@ -35,6 +35,8 @@ struct pba_probe_table {
     float build_ms;
     // what a call learned from its sample about this read set under (R, ring): whether the narrow window certifies its
     // overlaps.  The next target ranges against the same table skip the sample (three launches and their tails per call).
+    mutable uint32_t slice_max;    // largest / average candidate slice of a target in the last counted range of >= 1 024 targets (0: none yet)
+    mutable double slice_avg;
     mutable int wide_known;        // -1: not sampled yet, 0: start narrow, 1: start in the middle ring / at the reference band
     mutable double wide_R;
     mutable int wide_nb1;
@@ -203,41 +205,80 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     DevBuf d_cnt64;
     HIPCHK(hipMalloc(&d_cnt64.p, 32));
 
-    // 1. count: the slice of the candidate array every target needs
+    // 1. count: the slice of the candidate array every target needs -- or, for a later range of a table whose slices are
+    //    known to be big and even (capacity mode), no count pass: every target gets the same room, 1.25 x the largest slice
+    //    seen, and the fill pass reports what it needed; a target that outgrows its room sends the range through the
+    //    counted way after all.  Capacity mode leaves gaps in the candidate array, which only the pre-sort stage (2b) can
+    //    read, so it implies that stage.
     BufRef d_slice, d_off, d_valid, d_cand, d_tmp, d_out, d_small;
     // (the big arrays of a call live in the ctx's pool: at a million reads a target range needs 11 GB of candidates twice,
     // and mapping those anew for each of the 40 ranges took longer than everything the kernels do)
-    POOL(POOL_OVL_SMALL, sizeof(uint32_t) * 4 * ((size_t)nt + 1), d_small.p);
+    POOL(POOL_OVL_SMALL, sizeof(uint32_t) * 5 * ((size_t)nt + 1), d_small.p);
     d_slice.p = d_small.as<uint32_t>(); d_off.p = d_small.as<uint32_t>() + (nt + 1); d_valid.p = d_small.as<uint32_t>() + 2 * ((size_t)nt + 1);
-    (void)hipEventRecord(ctx->ev[2], ctx->stream);
-    if (tab->hashed) hipLaunchKernelGGL(k_ovl_count<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
-    else hipLaunchKernelGGL(k_ovl_count<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
-    std::vector<uint32_t> h_slice(nt + 1), h_off(nt + 1), h_valid(nt + 1);
-    HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipGetLastError());
-    uint64_t total = 0, max_cand = PBA_OVL_MAX_CANDIDATES;
+    uint32_t *const d_end = d_small.as<uint32_t>() + 4 * ((size_t)nt + 1);       // where every target's slice ends
+    std::vector<uint32_t> h_slice(nt + 1), h_off(nt + 1), h_valid(nt + 1), h_end(nt + 1);
+    uint64_t total = 0, extent = 0, max_cand = PBA_OVL_MAX_CANDIDATES;
     if (const char *e = getenv("PBA_OVL_MAX_CANDIDATES")) max_cand = std::min<uint64_t>(max_cand, (uint64_t)atoll(e));   // test hook: the limit at test sizes
+    uint64_t prekeep_min = 1ull << 29;                           // (2b)
+    if (const char *e = getenv("PBA_OVL_PREKEEP_MIN")) prekeep_min = (uint64_t)std::max(0LL, atoll(e));   // test hook: small inputs through the stage (or none)
+    uint32_t slice_cap = 0;
+    if (pl.nb1 != 0 && tab->slice_max > 0) {
+        int pct = 125;
+        if (const char *e = getenv("PBA_OVL_CAPFILL_PCT")) pct = atoi(e);         // test hook: 0 = never, small = overflow and fall back
+        const uint64_t c = (uint64_t)tab->slice_max * (uint64_t)std::max(0, pct) / 100 + (pct > 0 ? 64 : 0);
+        if (pct > 0 && (uint64_t)(tab->slice_avg * nt) >= prekeep_min && c * nt < max_cand && c < 0xFFFFFFFFull) slice_cap = (uint32_t)c;
+    }
     uint32_t biggest_small = 2;
     std::vector<uint32_t> big;                                   // targets whose slice outgrows one LDS sort
-    for (uint32_t i = 0; i < nt; ++i) {
-        h_off[i] = (uint32_t)total;
-        total += h_slice[i];
-        if (total >= max_cand) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
-        if (h_slice[i] <= PBA_IX_LDS_SORT_CAP) biggest_small = std::max(biggest_small, h_slice[i]);
-        else big.push_back(i);
-    }
-    h_off[nt] = (uint32_t)total;
-    HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-    POOL(POOL_OVL_CAND, sizeof(uint64_t) * (total + 1), d_cand.p);
+    bool cap_mode = false;
+    (void)hipEventRecord(ctx->ev[2], ctx->stream);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        cap_mode = attempt == 0 && slice_cap != 0;
+        if (attempt == 0 && !cap_mode) continue;
+        total = 0;
+        if (cap_mode) {
+            for (uint32_t i = 0; i <= nt; ++i) h_off[i] = (uint32_t)((uint64_t)i * slice_cap);
+            extent = (uint64_t)nt * slice_cap;
+        } else {
+            if (tab->hashed) hipLaunchKernelGGL(k_ovl_count<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+            else hipLaunchKernelGGL(k_ovl_count<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+            HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipGetLastError());
+            uint32_t mx = 0;
+            for (uint32_t i = 0; i < nt; ++i) {
+                h_off[i] = (uint32_t)total;
+                total += h_slice[i];
+                mx = std::max(mx, h_slice[i]);
+                if (total >= max_cand) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
+                if (h_slice[i] <= PBA_IX_LDS_SORT_CAP) biggest_small = std::max(biggest_small, h_slice[i]);
+                else big.push_back(i);
+            }
+            h_off[nt] = (uint32_t)total;
+            extent = total;
+            if (nt >= 1024) { tab->slice_max = mx; tab->slice_avg = (double)total / nt; }   // what a later range goes by
+        }
+        HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+        POOL(POOL_OVL_CAND, sizeof(uint64_t) * (extent + 1), d_cand.p);
 
-    // 2. fill: the candidates (all-ones where a slot belongs to the target's own probe or to another key)
-    if (total) {
-        if (tab->hashed) hipLaunchKernelGGL(k_ovl_fill<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>());
-        else hipLaunchKernelGGL(k_ovl_fill<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>());
-        HIPCHK(hipMemcpyAsync(h_valid.data(), d_valid.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        HIPCHK(hipMemsetAsync(d_valid.p, 0, sizeof(uint32_t) * (nt + 1), ctx->stream));
+        // 2. fill: the candidates (all-ones where a slot belongs to the target's own probe or to another key)
+        if (extent) {
+            uint32_t *const d_written = cap_mode ? d_slice.as<uint32_t>() : nullptr;
+            if (tab->hashed) hipLaunchKernelGGL(k_ovl_fill<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>(), cap_mode ? slice_cap : 0u, d_written);
+            else hipLaunchKernelGGL(k_ovl_fill<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>(), cap_mode ? slice_cap : 0u, d_written);
+            HIPCHK(hipMemcpyAsync(h_valid.data(), d_valid.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+            if (cap_mode) HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            HIPCHK(hipMemsetAsync(d_valid.p, 0, sizeof(uint32_t) * (nt + 1), ctx->stream));
+        }
+        if (cap_mode) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipGetLastError());
+            bool over = false;
+            for (uint32_t i = 0; i < nt; ++i) { over = over || h_slice[i] > slice_cap; total += h_slice[i]; }
+            if (over) { st.cap_overflow = 1; continue; }         // a slice outgrew its room: once more, counted
+        }
+        break;
     }
     (void)hipEventRecord(ctx->ev[3], ctx->stream);
 
@@ -246,10 +287,11 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     //     packed list (h_koff / h_kept) where it saw the slices (h_off / h_valid).  The time is the sort's in the statistics.
     // (measured, calls of 50 000 targets: 23 M candidates 0.081 s with the stage / 0.065 s without -- the few thousand dense
     // items that are left balance badly over 8 192 wavefronts --, 143 M 0.157 / 0.151, 573 M 0.333 / 0.330, 2.3 G 0.718 / 0.743,
-    // 9.2 G 1.68 / 1.99, 57 G 5.8 / 7.9)
-    uint64_t prekeep_min = 1ull << 29;
-    if (const char *e = getenv("PBA_OVL_PREKEEP_MIN")) prekeep_min = (uint64_t)std::max(0LL, atoll(e));   // test hook: small inputs through the stage (or none)
-    const bool prekeep = pl.nb1 != 0 && total >= prekeep_min && total > 0;
+    // 9.2 G 1.68 / 1.99, 57 G 5.8 / 7.9: prekeep_min = 2^29, above)
+    const bool prekeep = total > 0 && (cap_mode || (pl.nb1 != 0 && total >= prekeep_min));
+    st.cap_fill = cap_mode ? 1 : 0;
+    for (uint32_t i = 0; i < nt; ++i) h_end[i] = h_off[i] + h_slice[i];
+    HIPCHK(hipMemcpyAsync(d_end, h_end.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, ctx->stream));
     OvlCfg ocfg;
     ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2; ocfg.chunk = prekeep ? 1u : 0u;
     std::vector<uint32_t> h_kept, h_koff;                        // per target: candidates kept, and where they start in the packed list
@@ -275,7 +317,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         while (bloom_bits < PBA_OVL_BLOOM_MAX_BITS && (1ull << bloom_bits) < 2 * (total / nt)) ++bloom_bits;
         const size_t bloom_words = (size_t)nt << (bloom_bits - 5);
         const uint32_t n_tiles = (uint32_t)((n_it + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
-        POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles) + sizeof(uint16_t) * (total + 2), d_bloom.p);
+        POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles) + sizeof(uint16_t) * (extent + 2), d_bloom.p);
         HIPCHK(hipMemsetAsync(d_bloom.p, 0, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + 1), ctx->stream));
         uint32_t *const d_blanked = d_bloom.as<uint32_t>() + bloom_words;
         d_koff = d_blanked + (nt + 1);
@@ -288,13 +330,13 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         hipLaunchKernelGGL(k_ovl_ends, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reads->dev(), n, d_ends.as<OvlEnd>());
         const uint32_t g = (uint32_t)((n_it + 3) / 4);
         hipLaunchKernelGGL(k_ovl_pre, dim3(g), dim3(256), 0, ctx->stream, reads->dev(), t_lo, (uint32_t)n_it, d_items.as<uint2>(),
-                           d_off.as<uint32_t>(), d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), bloom_bits, d_blanked, d_slot);
-        hipLaunchKernelGGL(k_ovl_keep_count, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
+                           d_end, d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), bloom_bits, d_blanked, d_slot);
+        hipLaunchKernelGGL(k_ovl_keep_count, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_end,
                            d_slot, d_bloom.as<uint32_t>(), bloom_bits, d_before + 1);
         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
-        hipLaunchKernelGGL(k_ovl_keep_write, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_off.as<uint32_t>(),
+        hipLaunchKernelGGL(k_ovl_keep_write, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_end,
                            d_cand.as<uint64_t>(), d_slot, d_bloom.as<uint32_t>(), bloom_bits, d_before, d_tmp.as<uint64_t>());
         hipLaunchKernelGGL(k_ovl_keep_offsets, dim3((nt + 256) / 256), dim3(256), 0, ctx->stream, d_ipre1, d_before, nt, d_koff);
         h_koff.resize(nt + 1);

@@ -1295,6 +1295,27 @@ def test_locate_random_configs_vs_oracle():
     assert r.stdout.count("same=True") == 4
 
 
+def test_overlap_later_ranges_of_a_table_skip_the_count_pass(ctx, monkeypatch):
+    """Capacity mode: after one counted range of >= 1 024 targets the next ranges against the same probe table get equal room
+    per target (1.25 x the largest slice seen) instead of a count pass, and go through the pre-sort stage; a slice that
+    outgrows its room sends the range through the counted way again.  2 600 short reads in ranges of 1 300 targets: same rows
+    and counts as the row-sweep kernel in one call -- with the room as sized, with room for half the largest slice (every
+    later range overflows and is redone), and with the mode switched off."""
+    g = eng.synth_genome(401, 260000)
+    n, rl = 2600, 1500
+    reads, offs, _ = eng.synth_reads(402, g, n, rl, 0.02, 0.02, 0.02)
+    S = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    want, wst = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_ROWSWEEP)
+    assert len(want) > 10000
+    monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
+    for pct, n_cap, n_over in (("125", 1, 0), ("50", 1, 1), ("0", 0, 0)):
+        monkeypatch.setenv("PBA_OVL_CAPFILL_PCT", pct)
+        got, st = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=1300, kernel=PBA_KERNEL_BITVEC)
+        assert (got == want).all() and st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"], pct
+        assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (pct, st)
+
+
 def test_overlap_random_read_sets_bitvec_forms_vs_rowsweep():
     """tools/stress_overlap.py: all-vs-all on random read sets (60 ... 16 000 bases, 1-17 % error in indel- and substitution-
     heavy mixes, R 0.15-0.35, up to 4 000 reads) -- the bit-vector walk, with the pre-sort prefilter stage forced on and
