@@ -73,7 +73,7 @@ def parse():
                     help="locate mode: seconds after which the extra all-vs-all leg is given up and the headline line printed without it")
     ap.add_argument("--coverage", type=float, default=20.0, help="all-vs-all: genome = reads x read_len / coverage")
     ap.add_argument("--overlap-trials", type=int, default=32)
-    ap.add_argument("--targets-per-call", type=int, default=25_000)
+    ap.add_argument("--targets-per-call", type=int, default=40_000)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; gloo + PBA_BENCH_SHARE_GPU=1 rehearses the N > 1 paths with several ranks "
                          "on ONE GPU (a 1-GPU box; RCCL itself needs one GPU per rank)")
