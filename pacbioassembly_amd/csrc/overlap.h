@@ -204,7 +204,7 @@ k_ovl_count(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_
 template <bool HASHED>
 static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
 k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, uint64_t *cand, uint32_t *valid,
-           uint32_t slice_cap, uint32_t *written) {
+           uint32_t slice_cap, uint32_t *written, uint32_t coop_avg) {
     // slice_cap != 0: the slices were not counted first but given slice_cap slots each (the host's guess from an earlier
     // range of the same table); nothing is stored beyond that, written[t] says how many slots the target needed -- more than
     // slice_cap and the host runs the range again the counted way.
@@ -278,6 +278,30 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
         // tools/ubench_queue.hip)
         const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&cursor, lane == 0 ? Tot : 0u));
         __builtin_amdgcn_wave_barrier();                             // the run list is this wavefront's own: LDS keeps its order
+        if (Tot >= coop_avg * R) {
+            // Long runs (millions of reads: every position hits, ~4-15 probes per bucket): one run per lane would have every
+            // store instruction touch 64 different lines, 8 bytes each, and every probe-id load likewise.  The wavefront
+            // emits 64 CONSECUTIVE slots of the concatenated runs instead -- a lane finds the run of its slot in the prefix
+            // sums (r_rel, already in LDS) -- so stores and probe-id loads are whole lines.  Same slots, same values.
+            for (uint32_t slot = (uint32_t)lane; slot < Tot; slot += PBA_WAVE) {
+                uint32_t lo_r = 0, hi_r = R;                         // last run with r_rel <= slot
+                while (hi_r - lo_r > 1) {
+                    const uint32_t mid = (lo_r + hi_r) >> 1;
+                    if (r_rel[w][mid] <= slot) lo_r = mid; else hi_r = mid;
+                }
+                const uint32_t h = slot - r_rel[w][lo_r], e0 = r_s0[w][lo_r];
+                const uint32_t pe = h ? T.pid[e0 + h] : r_first[w][lo_r];
+                const uint32_t q = pe >> PBA_OVL_JD_BITS;
+                bool ok = q != t;
+                if (HASHED) ok = ok && T.pkey[e0 + h] == r_key[w][lo_r];
+                if (slice_cap == 0 || base + slot < slice_cap) {
+                    out[base + slot] = ok ? ((uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pe & ((1u << PBA_OVL_JD_BITS) - 1)) << PBA_OVL_ORD_BITS |
+                                             (uint64_t)r_ord[w][lo_r])
+                                          : ~0ull;
+                    myvalid += ok;
+                }
+            }
+        } else
         for (uint32_t r = (uint32_t)lane; r < R; r += PBA_WAVE) {
             const uint32_t e0 = r_s0[w][r], rel = r_rel[w][r], cnt = r_rel[w][r + 1] - rel;
             const uint64_t lowbits = (uint64_t)r_ord[w][r];

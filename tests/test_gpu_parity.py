@@ -573,13 +573,16 @@ def test_locate_ecoli_scale_genome_vs_oracle(ctx, oracle):
     assert wst["n_located"] > 250 and wst["n_pairs"] > wst["n_located"]
 
 
-@pytest.fixture(params=["sorted_whole", "prefiltered_before_the_sort"])
+@pytest.fixture(params=["sorted_whole", "prefiltered_before_the_sort", "scan_emits_cooperatively"])
 def prekeep(request, monkeypatch):
     """The all-vs-all tests run twice: as small calls run by default (every candidate is sorted and walked), and with the stage
     big calls get (>= 2^29 candidates) forced on -- the first prefilter stage before the sort, runs without a survivor
-    counted and dropped (overlap.h: k_ovl_pre / k_ovl_keep).  Same overlaps, same pair counts, both against the oracle."""
+    counted and dropped (overlap.h: k_ovl_pre / k_ovl_keep) -- and a third time with the fill pass emitting cooperatively, the form
+    it takes when runs are long.  Same overlaps, same pair counts, all against the oracle."""
     if request.param == "prefiltered_before_the_sort":
         monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
+    if request.param == "scan_emits_cooperatively":               # the fill pass's form for millions of reads (runs of >= 6 probes), forced
+        monkeypatch.setenv("PBA_OVL_COOP_AVG", "0")
     return request.param == "prefiltered_before_the_sort"
 
 
