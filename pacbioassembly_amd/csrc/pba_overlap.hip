@@ -264,8 +264,9 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         // 2. fill: the candidates (all-ones where a slot belongs to the target's own probe or to another key)
         if (extent) {
             uint32_t *const d_written = cap_mode ? d_slice.as<uint32_t>() : nullptr;
-            // runs of >= 6 probes on average: emit cooperatively (overlap.h).  Measured: a million reads (3.8 per run) scan
-            // 0.88 s one run per lane / 0.91 s cooperatively; two million (7.6 per run) 4.71 / 3.15 s
+            // runs of >= 6 probes on average: emit cooperatively (overlap.h).  Measured, second passes: a million reads (3.8
+            // per run) scan 0.88 s one run per lane / 0.91 s cooperatively; two million (7.6 per run) 3.41 / 3.12 s; four
+            // million (15 per run) 16.3 / 11.4 s
             uint32_t coop_avg = 6;
             if (const char *e = getenv("PBA_OVL_COOP_AVG")) coop_avg = (uint32_t)std::max(0, atoi(e));   // test hook: 0 = always
             if (tab->hashed) hipLaunchKernelGGL(k_ovl_fill<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>(), cap_mode ? slice_cap : 0u, d_written, coop_avg);
