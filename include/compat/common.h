@@ -13,8 +13,11 @@
 
 #include "pba.h"
 
+// common.h:22-28: DBG is defined there, unconditionally, and the mains test it (`#ifdef DBG` around the `found ...` /
+// `#trials` lines and the trial counter of spaced_seed.cpp:42,172,268,428,440) -- so it is part of the surface
 #ifndef PBA_COMPAT_QUIET
-#define LOG(...) fprintf(stderr, __VA_ARGS__)          // common.h:22-28 (DBG is defined there)
+#define DBG
+#define LOG(...) fprintf(stderr, __VA_ARGS__)
 #else
 #define LOG(...)
 #endif

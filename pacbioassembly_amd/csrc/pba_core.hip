@@ -93,6 +93,7 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
     memset(ctx->pool, 0, sizeof ctx->pool);
+    ctx->h_stage = nullptr; ctx->h_stage_cap = 0; ctx->attr_done = 0;
     memset(&ctx->ix_cache, 0, sizeof ctx->ix_cache);
     // (kernels that take more than the default 64 KB of dynamic LDS are given the attribute by the translation unit
     // that launches them: tu_attrs() in each .hip)
@@ -109,6 +110,7 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     (void)hipFree(ctx->d_queue);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (auto &b : ctx->pool) if (b.p) (void)hipFree(b.p);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->ix_cache.ent) (void)hipFree(ctx->ix_cache.ent);
     if (ctx->ix_cache.ent2) (void)hipFree(ctx->ix_cache.ent2);
     if (ctx->ix_cache.off) (void)hipFree(ctx->ix_cache.off);
@@ -120,6 +122,7 @@ int pba_ctx_trim(pba_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto &b : ctx->pool) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_cap = 0; }
     if (ctx->ix_cache.ent) (void)hipFree(ctx->ix_cache.ent);
     if (ctx->ix_cache.ent2) (void)hipFree(ctx->ix_cache.ent2);
     if (ctx->ix_cache.off) (void)hipFree(ctx->ix_cache.off);

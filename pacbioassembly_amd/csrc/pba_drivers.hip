@@ -218,10 +218,10 @@ k_spaced_round(IndexDev ix, SeqSetDev Rf, uint32_t rseq_id, int ref_org, SeqSetD
 }
 
 
-static void tu_attrs() {
-    static bool done = false;
-    if (done) return;
-    done = true;
+// (the attribute belongs to the current device: remembered per ctx, so a second ctx on another GPU sets it there too)
+static void tu_attrs(pba_ctx *ctx) {
+    if (ctx->attr_done & 2u) return;
+    ctx->attr_done |= 2u;
     PBA_BIG_LDS(k_locate<0>);
     PBA_BIG_LDS(k_spaced_round<0>);
 }
@@ -241,7 +241,7 @@ int pba_locate(pba_ctx *ctx, const pba_index *ix, const pba_seqs *target, uint32
     if (target->non_acgt || reads->non_acgt)   // locator.cpp compares raw bytes (an 'N' only matches an 'N'); codes would match it to T
         PBA_FAIL(PBA_E_ALPHABET, "pba_locate: a sequence set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
-    tu_attrs();
+    tu_attrs(ctx);
     const uint32_t n = reads->n;
     Plan pl;
     int st = make_plan(ctx, R, maxn, maxm, kernel, 1 + (int)(reads->max_len * R), &pl);
@@ -319,7 +319,7 @@ int spaced_round_subset(pba_ctx *ctx, const pba_index *ix, const pba_seqs *ref, 
         PBA_FAIL(PBA_E_TOOLONG, "sequence longer than the engine limit");
     if (ref->non_acgt || reads->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "pba_spaced_round: a sequence set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
-    tu_attrs();
+    tu_attrs(ctx);
     const uint32_t n = reads->n, n_first = subset ? n_subset : n;
     Plan pl;
     // a = reference window, b = read window: the shorter side bounds max_dst (seq_aligner.h:94-102)

@@ -23,7 +23,7 @@
 
 #define PBA_INTERNAL __attribute__((visibility("hidden")))
 // a kernel that takes more than the default 64 KB of dynamic LDS; every translation unit does this once for the kernels
-// it launches (tu_attrs() in each .hip; one process drives one GPU)
+// it launches, once per ctx (tu_attrs(ctx) in each .hip: the attribute is per device, and a ctx is bound to one)
 // (128 KB of dynamic LDS: the largest LDS sort and the largest band row, with room for a kernel's static arrays; a refused
 // attribute must not linger as the thread's last error)
 #define PBA_BIG_LDS(kernel)                                                                                            \
@@ -46,7 +46,11 @@ struct pba_ctx {
     // Work buffers of the drivers, kept between calls for the same reason (hipMalloc / hipFree of the 11 GB candidate
     // array of a million-read target range cost more than the kernels that fill it; the 4 MB of per-read rows of a
     // locate step cost 1 ms of a 50 ms step): grown on demand (pool_reserve), released by pba_ctx_trim or with the ctx.
-    struct { void *p; size_t cap; } pool[16];
+    struct { void *p; size_t cap; } pool[24];
+    // pinned host staging of the one-pair text entry points (pba_align_text*: one H2D and one D2H copy per call)
+    void *h_stage;
+    size_t h_stage_cap;
+    uint32_t attr_done;      // translation units whose big-LDS kernel attributes are set on this ctx's device (tu_attrs)
     // the entry / offset arrays of the index destroyed last, for the next build (a step of the locate loop builds and drops
     // one index: the hipFree / hipMalloc pair of its 40 MB cost 0.2 ms of a 48 ms step)
     struct { void *ent; size_t ent_cap; void *off; size_t off_cap; void *ent2; size_t ent2_cap; } ix_cache;
@@ -104,7 +108,8 @@ static const size_t kSlack = 1024;              // readable bytes before the fir
 
 // pool slots
 enum { POOL_OVL_CAND = 0, POOL_OVL_TMP, POOL_OVL_ITEMS, POOL_OVL_REDO, POOL_OVL_REDO_IN, POOL_OVL_OUT, POOL_OVL_SMALL,
-       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_OFFS, POOL_IX_WORK, POOL_OVL_BLOOM, POOL_OVL_ENDS };
+       POOL_LOC_ROWS, POOL_LOC_AUX, POOL_LOC_IDS, POOL_IX_OFFS, POOL_IX_WORK, POOL_OVL_BLOOM, POOL_OVL_ENDS,
+       POOL_TXT_IN, POOL_TXT_OUT, POOL_TXT_PAR, POOL_TXT_CST };
 // a buffer of at least `bytes` in pool slot `slot` (contents undefined); grows by reallocation with 1/8 headroom
 static inline int pool_reserve(pba_ctx *ctx, int slot, size_t bytes, void **out) {
     if (ctx->pool[slot].cap < bytes) {

@@ -4,10 +4,10 @@
 #include "pba_host.h"
 #include "overlap.h"
 
-static void tu_attrs() {
-    static bool done = false;
-    if (done) return;
-    done = true;
+// (the attribute belongs to the current device: remembered per ctx, so a second ctx on another GPU sets it there too)
+static void tu_attrs(pba_ctx *ctx) {
+    if (ctx->attr_done & 4u) return;
+    ctx->attr_done |= 4u;
     PBA_BIG_LDS(k_ovl_walk<0>);
 }
 
@@ -48,7 +48,7 @@ int pba_overlap_probes(pba_ctx *ctx, const pba_seqs *reads, uint32_t q_lo, uint3
     if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
     if (reads->n >= (1u << 24)) PBA_FAIL(PBA_E_TOOLONG, "at most 2^24 reads");
     HIPCHK(hipSetDevice(ctx->device));
-    tu_attrs();
+    tu_attrs(ctx);
     const uint32_t t2 = 2u * (uint32_t)max_trial;
     const uint64_t slots = (uint64_t)(q_hi - q_lo) * t2;
     DevBuf counter;
@@ -73,7 +73,7 @@ int pba_overlap_all(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, uint32_t
     if (!ctx || !reads || !n_out) return PBA_E_INVALID;
     if (max_trial < 1 || 2 * max_trial >= (1 << PBA_OVL_JD_BITS)) PBA_FAIL(PBA_E_INVALID, "max_trial must be in [1, 63]");
     HIPCHK(hipSetDevice(ctx->device));
-    tu_attrs();
+    tu_attrs(ctx);
     // 1. probe table of every read, built here (single-GPU form)
     const uint64_t pcap = (uint64_t)reads->n * 2u * (uint32_t)max_trial;
     DevBuf d_pent;
@@ -190,7 +190,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     if (reads->max_len > (uint32_t)kMaxSeqLen) PBA_FAIL(PBA_E_TOOLONG, "read longer than the engine limit");
     if (reads->non_acgt) PBA_FAIL(PBA_E_ALPHABET, "pba_overlap_all: the read set holds bytes outside ACGT");
     HIPCHK(hipSetDevice(ctx->device));
-    tu_attrs();
+    tu_attrs(ctx);
     *n_out = 0;
     pba_overlap_stats st;
     memset(&st, 0, sizeof st);

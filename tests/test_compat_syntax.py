@@ -17,3 +17,42 @@ def test_reference_main_compiles_against_compat_headers(name):
     p = subprocess.run(["g++", "-fsyntax-only", "-w", "-x", "c++", "-", "-I", os.path.join(ROOT, "include", "compat"),
                         "-I", os.path.join(ROOT, "include")], input=src, capture_output=True, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
+
+
+COMPAT_BINS = [os.path.join(ROOT, "oracle", "_ref", n) for n in ("locator_compat", "spaced_seed_compat")]
+
+
+@pytest.mark.skipif(not all(os.path.exists(p) for p in COMPAT_BINS), reason="oracle/_ref/*_compat are built where /root/reference exists")
+@pytest.mark.parametrize("exe", COMPAT_BINS)
+def test_compat_mains_really_bind_the_engine(exe):
+    """The reference's mains include their headers with quotes, so a plain `-Iinclude/compat src/locator.cpp` compiles them
+    against the reference's OWN headers (the compiler looks beside the source first) and yields the stock CPU program:
+    round 2's binaries were that.  oracle/Makefile feeds the source on stdin; what it builds must need libpba.so and import
+    the aligner entry point, and must NOT carry the reference's CPU aligner (its 1.25 GB matrix lives in .bss there)."""
+    dyn = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True, check=True).stdout
+    assert "libpba.so" in dyn, dyn
+    und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    for sym in ("pba_align_text_trace", "pba_ctx_create", "pba_encode16"):
+        assert sym in und, (sym, und)
+    # the stock binaries keep `state mat[MAXN][MAXM]` (hundreds of MB) inside the aligner object they `new`; the compat ones
+    # keep nothing of the kind: their .bss is the mains' own text buffers only (locator: 2 x 800 kB)
+    sizes = subprocess.run(["size", "-A", exe], capture_output=True, text=True, check=True).stdout
+    bss = [int(l.split()[1]) for l in sizes.splitlines() if l.startswith(".bss")][0]
+    assert bss < 64 << 20, sizes
+
+
+@pytest.mark.skipif(not os.path.exists(COMPAT_BINS[0]), reason="oracle/_ref/locator_compat is built where /root/reference exists")
+def test_compat_locator_has_no_cpu_path(tmp_path):
+    """Started with a device that does not exist, the reference's locator main linked against compat must stop at its
+    first alignment ("cannot create a device context") instead of printing rows: there is no CPU aligner inside it.  (With a
+    GPU the same binary prints the golden rows: tests/test_gpu_parity.py.)"""
+    from cons_scenarios import LOCATOR_CLI, locator_cli_inputs
+    contig, texts = locator_cli_inputs()
+    cf = tmp_path / "contig.txt"
+    cf.write_bytes(contig + b"\n")
+    env = dict(os.environ, PBA_DEVICE="4096",
+               LD_LIBRARY_PATH=os.path.join(ROOT, "pacbioassembly_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([COMPAT_BINS[0], str(cf), LOCATOR_CLI["pattern"]], input=b"\n".join(texts[:40]) + b"\n",
+                       capture_output=True, timeout=300, env=env)
+    assert r.returncode != 0 and r.stdout == b"", (r.returncode, r.stdout[:200])
+    assert b"cannot create a device context" in r.stderr, r.stderr[-500:]

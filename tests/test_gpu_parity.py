@@ -98,7 +98,16 @@ def check_result(got, exp, tag):
             assert int(got[k]) == exp[k], (tag, k, int(got[k]), exp)
 
 
-def test_align_text_golden(ctx):
+@pytest.fixture(params=["bitvec_when_acgt", "rowsweep_always"])
+def text_form(request, monkeypatch):
+    """The one-pair text entry points (the compat seq_aligner::align) take an ACGT-only pair through the bit-vector array and
+    anything else through the raw-byte row sweep; PBA_TEXT_ROWSWEEP=1 forces the row sweep for every pair.  Same answers."""
+    if request.param == "rowsweep_always":
+        monkeypatch.setenv("PBA_TEXT_ROWSWEEP", "1")
+    return request.param
+
+
+def test_align_text_golden(ctx, text_form):
     """Raw-byte semantics (seq_aligner.h:136), every golden case incl. the reference's own KATs."""
     for c in gold_json("align_kat.json"):
         got = ctx.align_text(c["a"].encode("latin1"), c["b"].encode("latin1"), c["R"], c["a_fwd"], c["b_fwd"])
@@ -180,7 +189,7 @@ def test_align_random_vs_oracle(ctx, oracle, kernel):
 
 
 # ----------------------------------------------------------------------------- traceback
-def test_traceback_golden_and_oracle(ctx, oracle):
+def test_traceback_golden_and_oracle(ctx, oracle, text_form):
     """edits[] / nedit (seq_aligner.h:214-233): every golden case through pba_align_text_trace (digest of the whole
     script produced by the reference), and the ACGT ones through the packed batch form against the oracle."""
     import hashlib
@@ -215,6 +224,57 @@ def test_traceback_golden_and_oracle(ctx, oracle):
         exp = oracle.align(a, b, 0.3, want_ops=True)
         check_result(res, exp, r)
         assert ops.tolist() == exp["ops"].tolist()
+
+
+def test_text_entry_points_clip_before_they_size_or_copy(ctx, oracle, text_form):
+    """seq_aligner.h:94-102 clips the longer accessor to the shorter + max_dst before anything else; locator.cpp:80-81 hands
+    align() the whole rest of its contig (up to 800 kb) and ref_seq.h:282-286 the whole rest of the reference.  Accessors of
+    100 kb, 300 kb and 790 kb (far beyond the engine's 65 000-element limit, which applies to what the DP sees) through
+    pba_align_text / _trace / _matrix, forward and backward, either side the long one, ACGT and with other bytes: result,
+    edit script and matrix cells equal the oracle's."""
+    g = eng.synth_genome(91, 800000)
+    reads, offs, starts = eng.synth_reads(92, g, 6, 2500)
+    gb = g.tobytes()
+    cases = []
+    for r, rest in zip(range(6), (100000, 300000, 790000, 100000, 300000, 70000)):
+        seg = reads[int(offs[r]):int(offs[r + 1])].tobytes()
+        p = int(starts[r]) if int(starts[r]) + rest <= 800000 else 800000 - rest
+        cases.append((seg, gb[p:p + rest], True, r))                                   # a read against the rest of the contig
+        cases.append((seg[::-1], gb[p:p + rest][::-1], False, r))                      # the same elements through backward accessors: the
+                                                                                       # ones the DP sees are the LAST bytes in memory
+    cases.append((gb[1000:201000], cases[0][0], True, "long_a"))                       # the a side is the long one
+    cases.append((cases[0][0].replace(b"G", b"N", 3), cases[0][1], True, "non_acgt"))  # raw-byte form whatever text_form says
+    cases.append((cases[2][0][:900] + b"acgt", gb[int(starts[1]):int(starts[1]) + 120000].lower(), True, "lower"))
+    n_ok = 0
+    for a, b, fwd, tag in cases:
+        exp = oracle.align(a, b, 0.3, fwd, fwd, want_ops=True)
+        assert exp["len_a"] <= 4000 and exp["len_b"] <= 4000 and max(len(a), len(b)) >= 70000
+        check_result(ctx.align_text(a, b, 0.3, fwd, fwd), exp, tag)
+        res, ops = ctx.align_text_trace(a, b, 0.3, fwd, fwd)
+        check_result(res, exp, tag)
+        assert ops.tolist() == exp["ops"].tolist(), tag
+        n_ok += exp["rc"] >= 0
+    assert n_ok >= 8                     # (reads whose locus lies too close to the contig end meet a shifted window: failures)
+    # the matrix of a clipped pair: every cell the reference's call wrote
+    a, b, fwd, _ = cases[0]
+    exp = oracle.align(a, b, 0.3, fwd, fwd)
+    res, cost, par, rows = ctx.align_text_matrix(a, b, 0.3, fwd, fwd)
+    check_result(res, exp, "matrix")
+    md = exp["max_dst"]
+    assert cost.shape == (exp["len_a"] + 1, 2 * md + 1) and rows == exp["len_a"]
+    rng = np.random.RandomState(3)
+    for i in rng.randint(1, exp["len_a"] + 1, 300):
+        j = int(np.clip(i + rng.randint(-md, md + 1), max(0, i - md), min(exp["len_b"], i + md)))
+        assert (int(cost[i, j - i + md]), int(par[i, j - i + md])) == oracle.cell(int(i), j), (i, j)
+    # limits: the reference's size guard (seq_aligner.h:104-107) answers -1 for what t_aligner cannot hold; without a guard the
+    # engine's own limit is an explicit error -- on the clipped lengths in both cases
+    big = gb[:70000]
+    r = ctx.align_text(big, gb[5:70005], 0.3, maxn=26000, maxm=6000)
+    assert int(r["rc"]) == -1 and int(r["len_a"]) == 70000 and int(r["max_dst"]) == 21001
+    with pytest.raises(eng.PbaError):
+        ctx.align_text(big, gb[5:70005], 0.3)
+    r = ctx.align_text(cases[0][0], gb, 0.3, maxn=26000, maxm=6000)           # 800 kb accessor, 2.5 kb read: fine
+    assert int(r["len_b"]) == 2500 + int(r["max_dst"])
 
 
 # ----------------------------------------------------------------------------- drivers
@@ -1227,11 +1287,19 @@ def test_reference_mains_linked_against_compat_print_what_they_print_on_the_cpu(
     exe2 = os.path.join(ROOT, "oracle", "_ref", "spaced_seed_compat")
     if not (os.path.exists(exe) and os.path.exists(exe2)):
         pytest.skip("oracle/_ref/*_compat are built only where /root/reference exists")
+    # they are the engine's clients, not the stock CPU programs (round 2's were: quote includes resolve beside the source
+    # first -- oracle/Makefile feeds the sources on stdin now): libpba.so is needed, and without a usable device they stop
+    for e in (exe, exe2):
+        assert "libpba.so" in subprocess.run(["readelf", "-d", e], capture_output=True, text=True, check=True).stdout
+        assert "pba_align_text_trace" in subprocess.run(["nm", "-D", "--undefined-only", e], capture_output=True, text=True, check=True).stdout
     gold = gold_json("locator_cli.json")
     contig, texts = locator_cli_inputs()
     cf = tmp_path / "contig.txt"
     cf.write_bytes(contig + b"\n")
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "pacbioassembly_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    bad = subprocess.run([exe, str(cf), LOCATOR_CLI["pattern"]], input=b"\n".join(texts[:30]) + b"\n", capture_output=True, timeout=600,
+                         env=dict(env, PBA_DEVICE="4096"))
+    assert bad.returncode != 0 and bad.stdout == b"" and b"cannot create a device context" in bad.stderr
     r = subprocess.run([exe, str(cf), LOCATOR_CLI["pattern"]], input=b"\n".join(texts) + b"\n", capture_output=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     rows = [[int(x) for x in line.split()] for line in r.stdout.decode().splitlines()]
