@@ -48,6 +48,8 @@ HBM_PEAK = 8.0e12            # B/s, MI355X spec (MI355X_MICROARCH.md)
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0
 VALU_PEAK_MEASURED = 256 * 4 * 2.4e9 / 2.5
 MASK_PAT = "111*11*11*1*1111"
+EXIT_LEG_LOST = 3            # the headline line was printed, the extra all-vs-all leg hung or lost a rank
+EXIT_HUNG = 4                # --mode overlap: the run did not finish within --timeout
 
 
 def parse():
@@ -71,6 +73,8 @@ def parse():
                     help="all-vs-all: reads of the WHOLE set (strong scaling); in locate mode the size of the extra leg, 0 = skip it")
     ap.add_argument("--overlap-timeout", type=int, default=420,
                     help="locate mode: seconds after which the extra all-vs-all leg is given up and the headline line printed without it")
+    ap.add_argument("--timeout", type=int, default=3000,
+                    help="--mode overlap: seconds after which a rank that has not finished gives up with exit code 4")
     ap.add_argument("--coverage", type=float, default=20.0, help="all-vs-all: genome = reads x read_len / coverage")
     ap.add_argument("--overlap-trials", type=int, default=32)
     ap.add_argument("--targets-per-call", type=int, default=40_000)
@@ -81,6 +85,24 @@ def parse():
                     help="no GPU work: every rank joins a gloo process group, the ranks are summed, rank 0 prints the census "
                          "(checks the launcher and the rendezvous on a box without GPUs)")
     return ap.parse_args()
+
+
+def socket_cores() -> int:
+    """Physical cores of socket 0 of this host (/proc/cpuinfo), 0 if it cannot be told."""
+    try:
+        cores, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = int(ln.split(":")[1])
+            elif ln.startswith("core id"):
+                core = int(ln.split(":")[1])
+            elif not ln.strip():
+                if phys == 0 and core is not None:
+                    cores.add(core)
+                phys = core = None
+        return len(cores)
+    except Exception:
+        return 0
 
 
 def host_cores() -> int:
@@ -123,7 +145,9 @@ def launch_ranks(n: int) -> int:
             for r, p in enumerate(procs):
                 if rcs[r] is None:
                     rcs[r] = p.poll()
-            if any(rc not in (None, 0) for rc in rcs):
+            # (a rank that left with EXIT_LEG_LOST has only lost the extra all-vs-all leg: the others get to their own
+            # fences -- rank 0 prints the headline line first -- and are not taken down)
+            if any(rc not in (None, 0, EXIT_LEG_LOST) for rc in rcs):
                 for r, p in enumerate(procs):
                     if rcs[r] is None:
                         p.terminate()
@@ -144,10 +168,15 @@ def launch_ranks(n: int) -> int:
             if p.poll() is None:
                 p.kill()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
     if bad:
         print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        # a rank that lost only the extra all-vs-all leg (EXIT_LEG_LOST) has printed the headline line first: it is relayed,
+        # and the failure stays visible in the exit code
+        if lines and all(rc in (0, EXIT_LEG_LOST) for rc in rcs):
+            print(lines[-1])
+            return EXIT_LEG_LOST
         return 1
-    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
     if not lines:
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         return 1
@@ -268,7 +297,9 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
 def guarded_overlap(a, ctx, rank, world, nthreads, headline):
     """The all-vs-all leg of a default run, fenced off from the headline line: whatever happens in it -- an exception on
     this rank, or a collective that never returns because another rank failed -- rank 0 still prints `headline` (with the
-    error noted in `overlap_strong`) and every rank leaves with exit code 0.  headline: rank 0's finished line, None elsewhere."""
+    error noted in `overlap_strong`) FIRST, and the process then leaves with EXIT_LEG_LOST, never 0: a hang or a lost rank
+    is visible to the launcher and in the run records.  (A single-rank exception is an ordinary result: the error is noted in
+    the line and the run ends normally.)  headline: rank 0's finished line, None elsewhere."""
     import threading
     if a.overlap_reads <= 0:
         return None
@@ -278,7 +309,8 @@ def guarded_overlap(a, ctx, rank, world, nthreads, headline):
         if headline is not None:
             headline["overlap_strong"] = {"error": msg}
             print(json.dumps(headline), flush=True)
-        os._exit(0)                                   # no teardown of a process group that may be wedged
+        print(f"bench.py rank {rank}: {msg}", file=sys.stderr, flush=True)
+        os._exit(EXIT_LEG_LOST)                       # no teardown of a process group that may be wedged; never restarted
 
     def watchdog():
         if not done.is_set():
@@ -350,7 +382,18 @@ def run_rank(a):
     nthreads = a.cpu_threads or max(1, host_cores() // (world if "LOCAL_WORLD_SIZE" in os.environ else 1))
 
     if a.mode == "overlap":
+        # bounded like the default leg: a wedged collective (a peer gone) or a hung kernel ends the rank with EXIT_HUNG
+        # after --timeout seconds instead of waiting for ever; an exception is an ordinary non-zero exit
+        import threading
+
+        def hung():
+            print(f"bench.py rank {rank}: --mode overlap did not finish within {a.timeout} s", file=sys.stderr, flush=True)
+            os._exit(EXIT_HUNG)
+        timer = threading.Timer(a.timeout, hung)
+        timer.daemon = True
+        timer.start()
         ov = overlap_leg(a, ctx, rank, world, nthreads, a.steps, a.warmup)
+        timer.cancel()
         if rank == 0:
             out = {"metric": METRIC, "value": ov["pairs_per_s"], "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
                    "warmup": a.warmup, "ms_per_step": round(1e3 * ov["seconds_per_step"], 3), "higher_is_better": True,
@@ -511,9 +554,18 @@ def run_rank(a):
         ct = time.perf_counter() - t0
         same = all((crow[c] == rows[c][:ns]).all() for c in ("found", "j", "pos", "cost", "seglen", "matlen_a",
                                                               "matlen_b", "n_pairs"))
+        sc = socket_cores()
+        per_core = cst["n_pairs"] / ct / nthreads
         cpu = {"value": round(cst["n_pairs"] / ct, 3), "unit": "pairs/s", "cores": nthreads, "kind": "port",
                "sample": f"first {ns} reads of the same workload (index build + locate), {ct:.1f} s wall, "
-                         f"{cst['n_pairs']} pairs, {cst['n_located']} located, {cst['n_cells'] / ct / 1e9:.2f} GCUPS",
+                         f"{cst['n_pairs']} pairs, {cst['n_located']} located, {cst['n_cells'] / ct / 1e9:.2f} GCUPS "
+                         f"(SURVEY 8d names the first 2 000 reads: ~4 x this sample's time on this box's {nthreads}-thread share, so the "
+                         f"bounded sample stays at {ns})",
+               # pairs/s per core and per socket.  One thread per core of this process's share; the socket figure
+               # is the per-core rate times the socket's physical cores (an extrapolation: this box grants a share, not a socket)
+               "pairs_per_s_per_core": round(per_core, 3), "socket_cores": sc or None,
+               "socket_pairs_per_s_extrapolated": round(per_core * sc, 1) if sc else None,
+               "gpu_vs_socket_extrapolated": round(value / (per_core * sc), 1) if sc else None,
                "gpu_rows_identical_on_sample": bool(same)}
         orc.release()
 

@@ -48,10 +48,11 @@ public:
     bool try_align(t_aligner *paligner, int pos, seq_accessor *pac_seg) {
         bool forward = pac_seg->is_forward();
         seq_accessor ac_ref = get_accessor(pos, forward);
+        paligner->want_edits(!locked);                                // an unlocked reference reads the script of every success (elect)
         if (paligner->align(&ac_ref, pac_seg) < 0) return false;      // the reference is `a`, the read is `b`
         if (paligner->matlen_a < OVERLAP_MIN) return false;
         if (locked) return true;
-        elect(pos, &paligner->edits[0], paligner->nedit, forward);
+        elect(pos, paligner->edits, paligner->nedit, forward);
         if (paligner->matlen_a == ac_ref.length()) {
             int add_len = pac_seg->length() - paligner->matlen_b;
             if (forward) append(pac_seg->pt(paligner->matlen_b), add_len);

@@ -98,6 +98,15 @@ static void aligner(const char *real_align_path) {   // test/aligner_test.cpp:44
         seq_accessor ref2((char *)ref_str.c_str(), true, ref_str.length());
         seq_accessor seg2((char *)seg_str.c_str(), true, seg_str.length());
         CHECK(-1 == pal->align(&seg2, &ref2));
+        // edits[] / nedit are produced on first use here: a failed align() in between leaves the last success's script, like
+        // the reference's array (seq_aligner.h:115 resets nedit only on the way to find_path) -- even one nobody had read yet
+        seq_accessor ref3((char *)"ACGTAACCGGTT", true, 10), seg3((char *)"CGTAACCGG", true, 9);
+        CHECK(10 == pal->align(&seg3, &ref3));                  // success, script not looked at
+        seg2.reset(0); ref2.reset(0);
+        CHECK(-1 == pal->align(&seg2, &ref2));                  // failure
+        CHECK(10 == pal->nedit && INSERT == pal->edits[0].op);  // the success's script
+        edit *raw = pal->edits;                                 // the array as a pointer (ref_seq.h:267 passes it on like this)
+        CHECK(raw[1].op == MATCH && raw[1].val == 'C');
     }
     {   // the matrix behind the alignment: get_cost / get_parent / set_cost / set_parent / mat (seq_aligner.h:81,131-134)
         // a = "ACGTAACC" vs b = "ACGAACCGG": D(i,j) by hand; max_dst = 1 + (int)(8 * 0.3) = 3

@@ -1380,11 +1380,17 @@ def test_overlap_later_ranges_of_a_table_skip_the_count_pass(ctx, monkeypatch):
     want, wst = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_ROWSWEEP)
     assert len(want) > 10000
     monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
-    for pct, n_cap, n_over in (("125", 1, 0), ("50", 1, 1), ("0", 0, 0)):
-        monkeypatch.setenv("PBA_OVL_CAPFILL_PCT", pct)
-        got, st = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=1300, kernel=PBA_KERNEL_BITVEC)
-        assert (got == want).all() and st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"], pct
-        assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (pct, st)
+    # ... and all of it a second time with the fill pass emitting cooperatively (the form runs of >= 6 probes get: millions of
+    # reads), which is how production sizes run capacity mode: its clipping at the slice's room and its count of what a target
+    # needed are live in the overflow-and-redo case
+    for coop in (None, "0"):
+        if coop is not None:
+            monkeypatch.setenv("PBA_OVL_COOP_AVG", coop)
+        for pct, n_cap, n_over in (("125", 1, 0), ("50", 1, 1), ("0", 0, 0)):
+            monkeypatch.setenv("PBA_OVL_CAPFILL_PCT", pct)
+            got, st = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=1300, kernel=PBA_KERNEL_BITVEC)
+            assert (got == want).all() and st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"], (coop, pct)
+            assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (coop, pct, st)
 
 
 def test_overlap_random_read_sets_bitvec_forms_vs_rowsweep():
@@ -1428,9 +1434,9 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
     env["PBA_BENCH_SHARE_GPU"] = "1"
     common = ["--reads", "3000", "--overlap-reads", "12000", "--steps", "1", "--warmup", "1", "--cpu-sample", "0"]
 
-    def run(*args):
+    def run(*args, rc=0):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, *common], env=env, capture_output=True, timeout=600)
-        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        assert p.returncode == rc, (p.returncode, p.stderr.decode()[-3000:])
         lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
         assert len(lines) == 1
         return json.loads(lines[0])
@@ -1445,11 +1451,17 @@ def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
     ovl = run("--gpus", "2", "--backend", "gloo", "--mode", "overlap")
     assert ovl["scaling"] == "strong" and ovl["overlap"]["pairs_per_step"] == b["pairs_per_step"]
     # a rank that dies in the extra all-vs-all leg costs the run that leg, not its headline line: the failing rank leaves,
-    # the other one gives the leg up at its timeout, rank 0 prints the line with the error noted, exit code 0
+    # the other one gives the leg up at its timeout, rank 0 prints the line with the error noted FIRST, and the run then ends
+    # with exit code 3 (bench.py: EXIT_LEG_LOST), never 0: the lost leg is visible to whoever started it
     for bad in ("1", "0"):
         env["PBA_BENCH_TEST_FAIL_RANK"] = bad
-        hurt = run("--gpus", "2", "--backend", "gloo", "--overlap-timeout", "25")
+        hurt = run("--gpus", "2", "--backend", "gloo", "--overlap-timeout", "25", rc=3)
         assert hurt["n_gpus"] == 2 and hurt["pairs_per_step"] == two["pairs_per_step"]
         assert "error" in hurt["overlap_strong"], hurt["overlap_strong"]
+    # --mode overlap is bounded too: a rank lost there ends the run non-zero (the failing rank's exception; its peer would
+    # leave at --timeout with code 4 if the launcher had not taken it down already)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--mode", "overlap",
+                        "--timeout", "40", *common], env=env, capture_output=True, timeout=600)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     del env["PBA_BENCH_TEST_FAIL_RANK"]
 
