@@ -400,16 +400,18 @@ typedef struct {
     uint32_t wide_first;           /* 1: a sample showed the narrow window rarely certifies, the rest went straight to the reference band */
     float table_ms;                /* build of the probe table this call scanned against (once per table, not per call) */
     uint32_t n_big_targets;        /* targets whose candidates outgrew one LDS sort and were cut into pieces of consecutive queries */
-    uint64_t n_prefiltered;        /* candidates of n_pairs that were dropped before the sort: every candidate of their (target, query)
-                                      run failed the reference's diagonal check within its first 32 rows (big calls only, else 0) */
-    uint32_t cap_fill;             /* 1: the candidate slices were not counted first but given equal room, sized by an earlier range of the table */
-    uint32_t cap_overflow;         /* 1: a slice outgrew that room and the range was run again the counted way */
+    uint64_t n_prefiltered;        /* bit-vector kernels: candidates that failed the reference's diagonal check within their first 32
+                                      rows where the scan found them -- pairs the reference aligned and dropped there: counted in
+                                      n_pairs, never written (row-sweep kernel: 0, every candidate is written, sorted and walked) */
+    uint32_t cap_fill;             /* 1: the survivors' slices were not sized by a census launch first but given equal room, sized by an earlier range of the table */
+    uint32_t cap_overflow;         /* 1: a slice outgrew that room and the range was scanned again with exact slices */
+    uint64_t n_listed;             /* candidates written, sorted and walked: the survivors of the scan's 32 rows (row-sweep kernel: all) */
 } pba_overlap_stats;
 
 /* Limits of the all-vs-all entry points (explicit PBA_E_TOOLONG beyond them, never a wrapped count):
  *   reads                      < PBA_OVL_MAX_READS       (a candidate packs the query id next to 23 bits of probe and ordinal)
  *   reads * 2 * max_trial      < PBA_OVL_MAX_PROBES      (a probe id is 32 bits)
- *   candidates of ONE call     < PBA_OVL_MAX_CANDIDATES  (offsets into the candidate array are 32 bits: go through the targets
+ *   LISTED candidates of ONE call < PBA_OVL_MAX_CANDIDATES (n_listed; offsets into the candidate array are 32 bits: go through the targets
  *                                                         in ranges [t_lo, t_hi) against one probe table -- BASELINE config 5,
  *                                                         10 M reads, takes ~4 000 targets per call)
  *   max_trial                  in [1, 63], read length <= 65 000 */

@@ -36,7 +36,7 @@ class PbaOverlapStats(C.Structure):
     _fields_ = [("n_probe_entries", C.c_uint64), ("n_candidates", C.c_uint64), ("n_pairs", C.c_uint64),
                 ("n_overlaps", C.c_uint64), ("n_redo", C.c_uint64), ("scan_ms", C.c_float), ("sort_ms", C.c_float),
                 ("walk_ms", C.c_float), ("wide_first", C.c_uint32), ("table_ms", C.c_float), ("n_big_targets", C.c_uint32),
-                ("n_prefiltered", C.c_uint64), ("cap_fill", C.c_uint32), ("cap_overflow", C.c_uint32)]
+                ("n_prefiltered", C.c_uint64), ("cap_fill", C.c_uint32), ("cap_overflow", C.c_uint32), ("n_listed", C.c_uint64)]
 
 
 class PbaProfile(C.Structure):

@@ -8,17 +8,22 @@
 // multi-GPU run all-gathers), the targets' positions are scanned against that table:
 //   k_probe_emit : one probe entry (key << 32 | probe id) per (query, j, direction), key 0 dropped
 //   k_pt_*       : the entries into a direct-address probe table (bucket offsets + entries + one presence bit per key)
-//   k_ovl_count  : one workgroup per target, 16 positions per thread from one 8-byte load: the size of its candidate slice
-//   k_ovl_fill   : the same walk plus the entries: one candidate per matching probe of another read,
-//                  candidate = query << 23 | (2j + backward) << 16 | ordinal
-//   (per-target sort of the candidates in LDS; 64-bit order = query, then j, forward before backward, then the
-//    seedmap's list order -- exactly the order spaced_seed tries them in; big targets are cut into pieces of
-//    consecutive queries first: k_ovl_split, then k_seg_sort piece by piece)
-//   (calls with >= 2^29 candidates: k_ovl_ends / k_ovl_pre / k_ovl_keep_* first -- the first prefilter stage over the unsorted
-//    list, only the runs that can hold a success are sorted and walked, the rest are counted; further down)
-//   k_ovl_walk   : persistent wavefronts walk a target's candidates, align until the first success per query;
+//   k_ovl_scan   : (bit-vector kernels) one workgroup per target, 16 positions per thread from one 8-byte load; every
+//                  candidate -- (position, matching probe of another read) -- gets a lane, which has the probe's record
+//                  (query, its length, the 32 elements its alignment starts with: 16 bytes beside the probe id in the
+//                  table), takes the target's 32 elements at the hit and runs the FIRST 32 ROWS of the reference's sweep
+//                  right there (prefilter.h).  98.6 % of the candidates fail the reference's diagonal check in those
+//                  rows: they are pairs the reference aligned and dropped -- counted, never written.  The survivors
+//                  (candidate = query << 23 | (2j + backward) << 16 | ordinal) go to the target's slice.
+//   (per-target sort of the survivors in LDS; 64-bit order = query, then j, forward before backward, then the
+//    seedmap's list order -- exactly the order spaced_seed tries them in)
+//   k_ovl_walk   : persistent wavefronts walk a target's survivors, align until the first success per query;
 //                  (target, query) runs whose narrow-window verdict is not certified (or whose narrow pass was given up: it
 //                  was heading past what the window certifies) are parked and resumed by later launches in wider rings
+//   k_ovl_after  : per success, the candidates of its (target, query) run the reference never got to (it stops at the first
+//                  success): pairs = candidates - those
+//   k_ovl_count / k_ovl_fill : the row-sweep kernel's form (the cross-check: no prefilter, no windows): every candidate is
+//                  written, sorted and walked
 #ifndef PBA_OVERLAP_H
 #define PBA_OVERLAP_H
 
@@ -65,22 +70,24 @@ struct HeadTail {
 
 // ---------------------------------------------------------------------------------------------------------------
 // The probe table: a direct-address CSR over the probe keys ("LDS-staged hash buckets" of the north star, sized for HBM:
-// the table of a million reads is 64 MB of bucket offsets + 256 MB of entries and stays resident).
+// the table of a million reads is 64 MB of bucket offsets + 1 GB of entry records and stays resident).
 //   bucket(key) = the key's care bits gathered into one number when the mask has <= PBA_PT_MAX_BITS of them (every key
-//                 its own bucket: a lookup is ONE load of two adjacent offsets, no search, no key compare), else a
+//                 its own bucket: a lookup is ONE 8-byte load of two adjacent offsets, no search, no key compare), else a
 //                 multiplicative hash into 2^PBA_PT_MAX_BITS buckets (HASHED: the entry's key is kept and compared)
-//   rec[b]   = { first entry of bucket b in pid[] (and pkey[] when HASHED), pid of that first entry }: one 16-byte load of
-//              rec[b], rec[b+1] gives the bucket's extent AND its first entry -- five buckets in six hold a single entry
-//              up to ~100 k reads, so the lookup of a position costs ONE line from beyond L2, which is what the scan is
-//              bound by (PMC: both passes sit at ~53 G random 64-byte lines per second from the Infinity Cache)
-//   start[]  = the same offsets as a plain u32 array (the table is built on it; 4 B per bucket instead of 8 for the count pass)
+//   start[b] = first entry of bucket b in pid[] / prec[] (and pkey[] when HASHED); start[b + 1] ends it
 //   pid[i]   = query << 7 | (2j + backward)
+//   prec[i]  = { pid[i], length of the query, low / high bit plane of the 32 ELEMENTS the probe's alignment starts with }:
+//              element r = base j + r of the query forward, base slen - j - 1 - r backward (spaced_seed.cpp:274-275), i.e.
+//              the columns of the first 32 rows of the reference's sweep.  With it a candidate's first diagonal checks
+//              need nothing of the query but this record, which arrives coalesced with its bucket -- the scan used to
+//              write every candidate and a later pass fetched one scattered line of the query per candidate.
+//              Filled from the read set on first use (k_pt_ctx): the exchanged object stays the 8-byte probe entry.
 //   presence = one bit per bucket (2 MB for the weight-12 masks of seeds.txt: resident in every XCD's L2), consulted
 //              first -- with 20 k reads 12 of 13 positions stop there, with a million reads none do
 #define PBA_PT_MAX_BITS 26
 struct ProbeTab {
     uint32_t *start, *pid, *pkey, *presence;
-    uint2 *rec;
+    uint4 *prec;
     uint32_t mask, mv[5];
     int bits;
 };
@@ -122,27 +129,33 @@ k_pt_fill(const uint64_t *in, uint64_t n, ProbeTab T, uint32_t *cursor, uint32_t
     if (HASHED) T.pkey[slot] = key;
 }
 
-// rec[b] = { start[b], pid[start[b]] } once the entries are in place
+// prec[i] once the entries are in place and the read set is at hand (ProbeTab above)
 static __global__ void __launch_bounds__(256)
-k_pt_pack(ProbeTab T, uint64_t n_buckets_plus_1, uint32_t n_entries) {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_buckets_plus_1) return;
-    const uint32_t s = T.start[b];
-    T.rec[b] = make_uint2(s, s < n_entries ? T.pid[s] : 0u);
+k_pt_ctx(ProbeTab T, SeqSetDev Rd, uint32_t n_entries) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint32_t pe = T.pid[i], q = pe >> PBA_OVL_JD_BITS, jd = pe & ((1u << PBA_OVL_JD_BITS) - 1);
+    const int slen = (int)Rd.len[q], j = (int)(jd >> 1);
+    const bool fwd = (jd & 1u) == 0;
+    const int s_off = fwd ? j : slen - j - 1;                           // spaced_seed.cpp:274 (pos + 15 backward, pos = slen - j - 16)
+    uint32_t lo = 0, hi = 0;
+    if (slen - j >= PBA_PRE_ROWS) load_planes32(fetch_of(Rd, q, s_off, fwd ? 1 : -1), 0, lo, hi);   // (shorter: the prefilter does not apply)
+    T.prec[i] = make_uint4(pe, (uint32_t)slen, lo, hi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The scan: one workgroup per target, every thread takes 16 consecutive positions from ONE 8-byte load of packed bases
 // (0.25 B per position, the algorithmic read) and looks their keys up with all 16 loads of a stage in flight at once --
 // the scan is bound by the rate at which the memory system serves random lines, not by arithmetic.
-//   k_ovl_count : candidates a target will produce at most (probe entries in the buckets its keys reach) -> its slice of
-//                 the candidate array.  One presence bit and, behind it, one offset pair per position; no entry is read.
-//   k_ovl_fill  : the same walk plus the entries: candidate = query << 23 | (2j + backward) << 16 | ordinal for every
-//                 entry of another read (and, HASHED, of the same key); the target's own probes and foreign keys leave
-//                 all-ones slots, which sort to the end of the slice.  valid[tl] = real candidates.
-// Positions that found entries ("runs") are compacted into LDS per wavefront, then taken 64 runs at a time, one run per
-// lane: the 16-positions-per-thread walk stays convergent and the emission is balanced whatever the hit density
-// (0.08 per position at 20 k reads, 3.8 at a million).
+//   k_ovl_scan  : the form of the bit-vector kernels: every candidate gets a lane, its first 32 rows run there, only the
+//                 survivors are written (below)
+//   k_ovl_count : the row-sweep form, pass 1: candidates a target will produce at most (probe entries in the buckets its keys
+//                 reach) -> its slice of the candidate array.  One presence bit and one offset pair per position.
+//   k_ovl_fill  : pass 2: candidate = query << 23 | (2j + backward) << 16 | ordinal for every entry of another read (and,
+//                 HASHED, of the same key); the target's own probes and foreign keys leave all-ones slots, which sort to the
+//                 end of the slice.  valid[tl] = real candidates.
+// Positions that found entries ("runs") are compacted into LDS per wavefront: the 16-positions-per-thread walk stays
+// convergent and the emission is balanced whatever the hit density (0.08 per position at 20 k reads, 3.8 at a million).
 #define PBA_OVL_PPT 16                                         // positions per thread and step
 #define PBA_OVL_WAVES 4                                        // wavefronts per workgroup
 #ifndef PBA_OVL_HALF
@@ -201,18 +214,59 @@ k_ovl_count(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, uint32_
     }
 }
 
+// the runs of one round of a wavefront's step, compacted into its part of LDS: first entry, first slot (relative to the round's
+// reservation; r_rel[R] = the round's total), ordinal of the position, key (HASHED)
+#define PBA_OVL_RUN_LISTS(HASHEDV)                                                         \
+    __shared__ uint32_t r_s0[PBA_OVL_WAVES][PBA_OVL_RUNS];                                 \
+    __shared__ uint32_t r_rel[PBA_OVL_WAVES][PBA_OVL_RUNS + 1];                            \
+    __shared__ uint16_t r_ord[PBA_OVL_WAVES][PBA_OVL_RUNS];                                \
+    __shared__ uint32_t r_key[(HASHEDV) ? PBA_OVL_WAVES : 1][(HASHEDV) ? PBA_OVL_RUNS : 1]
+
+// One step of a thread: its 16 positions' keys -> presence -> bucket extents (s0[k], n[k]; n = 0: nothing there)
+#define PBA_OVL_LOOKUP16()                                                                                     \
+    uint32_t b[PBA_OVL_PPT], pw[PBA_OVL_PPT], key[PBA_OVL_PPT];                                                \
+    _Pragma("unroll") for (int k = 0; k < PBA_OVL_PPT; ++k) {                                                  \
+        key[k] = __builtin_bswap32((uint32_t)((be << (2 * k)) >> 32)) & T.mask;                                \
+        const bool ok = live && key[k] != 0u && tw.ord_of(16 * c + k) >= 0;          /* ref_seq.h:300,307 */   \
+        b[k] = ok ? pt_bucket<HASHED>(T, key[k]) : 0xFFFFFFFFu;                                                \
+        pw[k] = T.presence[ok ? b[k] >> 5 : 0u];                                                               \
+    }                                                                                                          \
+    uint32_t s0[PBA_OVL_PPT], n[PBA_OVL_PPT];                                                                  \
+    _Pragma("unroll") for (int k = 0; k < PBA_OVL_PPT; ++k) {                                                  \
+        const bool hit = b[k] != 0xFFFFFFFFu && ((pw[k] >> (b[k] & 31)) & 1u);                                 \
+        uint2 se;                                                   /* the bucket's offset pair in one 8-byte load */ \
+        __builtin_memcpy(&se, T.start + (hit ? b[k] : 0u), 8);                                                 \
+        s0[k] = se.x; n[k] = hit ? se.y - se.x : 0u;                                                           \
+    }
+
+// ... and the runs of positions [h0, h0 + PBA_OVL_HALF) of every lane into the wavefront's lists: R runs, Tot entries
+// (both wave-uniform); `continue`s the enclosing loop when there is none
+#define PBA_OVL_COMPACT()                                                                                      \
+    uint32_t tot_h = 0, nruns_h = 0;                                                                           \
+    _Pragma("unroll") for (int k = h0; k < h0 + PBA_OVL_HALF; ++k) { tot_h += n[k]; nruns_h += n[k] != 0u; }   \
+    uint32_t run_at = nruns_h, slot_at = tot_h;        /* exclusive prefix over the lanes */                   \
+    _Pragma("unroll") for (int d = 1; d < PBA_WAVE; d <<= 1) {                                                 \
+        const uint32_t a_ = __shfl_up(run_at, d, PBA_WAVE), s_ = __shfl_up(slot_at, d, PBA_WAVE);              \
+        if (lane >= d) { run_at += a_; slot_at += s_; }                                                        \
+    }                                                                                                          \
+    const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)run_at, PBA_WAVE - 1);                         \
+    const uint32_t Tot = (uint32_t)__builtin_amdgcn_readlane((int)slot_at, PBA_WAVE - 1);                      \
+    if (R == 0) continue;                                                                                      \
+    run_at -= nruns_h; slot_at -= tot_h;                                                                       \
+    _Pragma("unroll") for (int k = h0; k < h0 + PBA_OVL_HALF; ++k) {                                           \
+        if (n[k]) {                                                                                            \
+            r_s0[w][run_at] = s0[k]; r_rel[w][run_at] = slot_at; r_ord[w][run_at] = (uint16_t)tw.ord_of(16 * c + k); \
+            if (HASHED) r_key[w][run_at] = key[k];                                                             \
+            ++run_at; slot_at += n[k];                                                                         \
+        }                                                                                                      \
+    }                                                                                                          \
+    if (lane == PBA_WAVE - 1) r_rel[w][R] = Tot;                                                               \
+    __builtin_amdgcn_wave_barrier();                 /* the lists are this wavefront's own: LDS keeps its order */
+
 template <bool HASHED>
 static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
-k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, uint64_t *cand, uint32_t *valid,
-           uint32_t slice_cap, uint32_t *written, uint32_t coop_avg) {
-    // slice_cap != 0: the slices were not counted first but given slice_cap slots each (the host's guess from an earlier
-    // range of the same table); nothing is stored beyond that, written[t] says how many slots the target needed -- more than
-    // slice_cap and the host runs the range again the counted way.
-    __shared__ uint32_t r_s0[PBA_OVL_WAVES][PBA_OVL_RUNS];         // first entry of the run
-    __shared__ uint32_t r_rel[PBA_OVL_WAVES][PBA_OVL_RUNS + 1];    // its first slot, relative to the step's reservation
-    __shared__ uint16_t r_ord[PBA_OVL_WAVES][PBA_OVL_RUNS];        // ordinal of the position
-    __shared__ uint32_t r_first[PBA_OVL_WAVES][PBA_OVL_RUNS];      // its first entry (came with the bucket's record)
-    __shared__ uint32_t r_key[HASHED ? PBA_OVL_WAVES : 1][HASHED ? PBA_OVL_RUNS : 1];
+k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *cand_off, uint64_t *cand, uint32_t *valid) {
+    PBA_OVL_RUN_LISTS(HASHED);
     __shared__ uint32_t cursor, nvalid;
     const uint32_t tl = blockIdx.x, t = t_lo + tl;
     const int lane = threadIdx.x & (PBA_WAVE - 1), w = threadIdx.x / PBA_WAVE;
@@ -230,102 +284,143 @@ k_ovl_fill(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
         const int c = st * PBA_WAVE * PBA_OVL_WAVES + (int)threadIdx.x;
         const bool live = c < tw.nchunks;
         const uint64_t be = live ? chunk_bits(seq, (uint32_t)c) : 0ull;
-        uint32_t b[PBA_OVL_PPT], pw[PBA_OVL_PPT], key[PBA_OVL_PPT];
-#pragma unroll
-        for (int k = 0; k < PBA_OVL_PPT; ++k) {
-            key[k] = __builtin_bswap32((uint32_t)((be << (2 * k)) >> 32)) & T.mask;
-            const bool ok = live && key[k] != 0u && tw.ord_of(16 * c + k) >= 0;
-            b[k] = ok ? pt_bucket<HASHED>(T, key[k]) : 0xFFFFFFFFu;
-            pw[k] = T.presence[ok ? b[k] >> 5 : 0u];
-        }
-        uint32_t s0[PBA_OVL_PPT], n[PBA_OVL_PPT], first[PBA_OVL_PPT];
-#pragma unroll
-        for (int k = 0; k < PBA_OVL_PPT; ++k) {
-            const bool hit = b[k] != 0xFFFFFFFFu && ((pw[k] >> (b[k] & 31)) & 1u);
-            uint4 se;                                                   // rec[b], rec[b + 1] in one 16-byte load
-            __builtin_memcpy(&se, T.rec + (hit ? b[k] : 0u), 16);
-            s0[k] = se.x; n[k] = hit ? se.z - se.x : 0u; first[k] = se.y;
-        }
-        // the runs of the step are compacted and emitted in PBA_OVL_PPT / PBA_OVL_HALF rounds (tuning hook; measured at 100 k
-        // reads: one round of 16 -> 34.7 ms for the scan, two of 8 (half the LDS, twice the workgroups per CU) -> 36.4)
+        PBA_OVL_LOOKUP16();
 #pragma unroll
         for (int h0 = 0; h0 < PBA_OVL_PPT; h0 += PBA_OVL_HALF) {
-        uint32_t tot_h = 0, nruns_h = 0;
-#pragma unroll
-        for (int k = h0; k < h0 + PBA_OVL_HALF; ++k) { tot_h += n[k]; nruns_h += n[k] != 0u; }
-        // exclusive prefix over the lanes: where this lane's runs go in the run list, and its entries in the reservation
-        uint32_t run_at = nruns_h, slot_at = tot_h;
-#pragma unroll
-        for (int d = 1; d < PBA_WAVE; d <<= 1) {
-            const uint32_t a = __shfl_up(run_at, d, PBA_WAVE), s = __shfl_up(slot_at, d, PBA_WAVE);
-            if (lane >= d) { run_at += a; slot_at += s; }
-        }
-        const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)run_at, PBA_WAVE - 1);
-        const uint32_t Tot = (uint32_t)__builtin_amdgcn_readlane((int)slot_at, PBA_WAVE - 1);
-        if (R == 0) continue;                                        // (wave-uniform)
-        run_at -= nruns_h; slot_at -= tot_h;
-#pragma unroll
-        for (int k = h0; k < h0 + PBA_OVL_HALF; ++k) {
-            if (n[k]) {
-                r_s0[w][run_at] = s0[k]; r_rel[w][run_at] = slot_at; r_ord[w][run_at] = (uint16_t)tw.ord_of(16 * c + k);
-                r_first[w][run_at] = first[k];
-                if (HASHED) r_key[w][run_at] = key[k];
-                ++run_at; slot_at += n[k];
-            }
-        }
-        if (lane == PBA_WAVE - 1) r_rel[w][R] = Tot;
-        // (every lane calls the atomic, lane 0 adds: the lane-0-only form is what ROCm 7.2's clang miscompiles in loops,
-        // tools/ubench_queue.hip)
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&cursor, lane == 0 ? Tot : 0u));
-        __builtin_amdgcn_wave_barrier();                             // the run list is this wavefront's own: LDS keeps its order
-        if (Tot >= coop_avg * R) {
-            // Long runs (millions of reads: every position hits, ~4-15 probes per bucket): one run per lane would have every
-            // store instruction touch 64 different lines, 8 bytes each, and every probe-id load likewise.  The wavefront
-            // emits 64 CONSECUTIVE slots of the concatenated runs instead -- a lane finds the run of its slot in the prefix
-            // sums (r_rel, already in LDS) -- so stores and probe-id loads are whole lines.  Same slots, same values.
-            for (uint32_t slot = (uint32_t)lane; slot < Tot; slot += PBA_WAVE) {
-                uint32_t lo_r = 0, hi_r = R;                         // last run with r_rel <= slot
-                while (hi_r - lo_r > 1) {
-                    const uint32_t mid = (lo_r + hi_r) >> 1;
-                    if (r_rel[w][mid] <= slot) lo_r = mid; else hi_r = mid;
-                }
-                const uint32_t h = slot - r_rel[w][lo_r], e0 = r_s0[w][lo_r];
-                const uint32_t pe = h ? T.pid[e0 + h] : r_first[w][lo_r];
-                const uint32_t q = pe >> PBA_OVL_JD_BITS;
-                bool ok = q != t;
-                if (HASHED) ok = ok && T.pkey[e0 + h] == r_key[w][lo_r];
-                if (slice_cap == 0 || base + slot < slice_cap) {
-                    out[base + slot] = ok ? ((uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pe & ((1u << PBA_OVL_JD_BITS) - 1)) << PBA_OVL_ORD_BITS |
-                                             (uint64_t)r_ord[w][lo_r])
-                                          : ~0ull;
+            PBA_OVL_COMPACT();
+            // (every lane calls the atomic, lane 0 adds: the lane-0-only form is what ROCm 7.2's clang miscompiles in loops,
+            // tools/ubench_queue.hip)
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&cursor, lane == 0 ? Tot : 0u));
+            for (uint32_t r = (uint32_t)lane; r < R; r += PBA_WAVE) {           // one run per lane
+                const uint32_t e0 = r_s0[w][r], rel = r_rel[w][r], cnt = r_rel[w][r + 1] - rel;
+                const uint64_t lowbits = (uint64_t)r_ord[w][r];
+                const uint32_t want = HASHED ? r_key[w][r] : 0u;
+                uint64_t *o = out + base + rel;
+                for (uint32_t h = 0; h < cnt; ++h) {
+                    const uint32_t pe = T.pid[e0 + h];
+                    const uint32_t q = pe >> PBA_OVL_JD_BITS;
+                    bool ok = q != t;
+                    if (HASHED) ok = ok && T.pkey[e0 + h] == want;
+                    o[h] = ok ? ((uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pe & ((1u << PBA_OVL_JD_BITS) - 1)) << PBA_OVL_ORD_BITS | lowbits)
+                              : ~0ull;
                     myvalid += ok;
                 }
             }
-        } else
-        for (uint32_t r = (uint32_t)lane; r < R; r += PBA_WAVE) {
-            const uint32_t e0 = r_s0[w][r], rel = r_rel[w][r], cnt = r_rel[w][r + 1] - rel;
-            const uint64_t lowbits = (uint64_t)r_ord[w][r];
-            const uint32_t want = HASHED ? r_key[w][r] : 0u;
-            uint64_t *o = out + base + rel;
-            const uint32_t room = slice_cap == 0 ? cnt : (base + rel >= slice_cap ? 0u : min(cnt, slice_cap - (base + rel)));
-            for (uint32_t h = 0; h < room; ++h) {
-                const uint32_t pe = h ? T.pid[e0 + h] : r_first[w][r];
-                const uint32_t q = pe >> PBA_OVL_JD_BITS;
-                bool ok = q != t;
-                if (HASHED) ok = ok && T.pkey[e0 + h] == want;
-                o[h] = ok ? ((uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)(pe & ((1u << PBA_OVL_JD_BITS) - 1)) << PBA_OVL_ORD_BITS | lowbits)
-                          : ~0ull;
-                myvalid += ok;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                             // before the next round overwrites the list
+            __builtin_amdgcn_wave_barrier();                             // before the next round overwrites the lists
         }
     }
 #pragma unroll
     for (int d = 1; d < PBA_WAVE; d <<= 1) myvalid += __shfl_xor(myvalid, d, PBA_WAVE);
     if (lane == 0 && myvalid) atomicAdd(&nvalid, myvalid);
     __syncthreads();
-    if (threadIdx.x == 0) { valid[tl] = nvalid; if (written) written[tl] = cursor; }
+    if (threadIdx.x == 0) valid[tl] = nvalid;
+}
+
+struct OvlCfg {
+    double R;
+    int overlap_min;
+    int row_cap;      // u16 cells of LDS per wavefront
+    uint32_t t2;
+    uint32_t chunk;   // work items a wavefront of the walk takes at a time when there are >= 2^20 of them (0: PBA_OVL_CHUNK)
+    int fused;        // the lists hold survivors of the scan's first 32 rows only (k_ovl_scan); pairs are counted by the scan and k_ovl_after
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scan of the bit-vector kernels.  Same walk over the target's positions, same runs -- but every candidate of a round
+// gets a LANE (the wavefront takes 64 consecutive slots of the concatenated runs at a time, a lane finds the run of its slot
+// in the prefix sums that are in LDS anyway: whole-line loads of the records whatever the run lengths) and the lane settles
+// it as far as 32 rows can: decode (spaced_seed.cpp:274-286, ref_seq.h:282-286), the OVERLAP_MIN gate, the target's 32
+// elements at the hit against the 32 elements of the probe's record through one Myers block (prefilter.h: exactly the
+// reference's diagonal checks of rows 11..32, seq_aligner.h:185).  A candidate that fails is a pair the reference aligned
+// and dropped at that row: it is COUNTED and never exists in memory.  A survivor (1.4 % at R = 0.30, plus every true
+// overlap) is written to the target's slice.  What the reference would not have aligned at all -- candidates of a (target,
+// query) run behind that run's first success -- is taken off the count afterwards, per success (k_ovl_after).
+//   surv_off == nullptr: nothing is written (the first range of a table: how much room a target needs)
+//   slice_cap          : slots a target may write (equal room from an earlier range's census, or its exact need)
+//   needed[tl]         : survivors the target produced, written or not (> slice_cap: the host runs the range again, exact)
+//   totals[0] += seed matches (entries of other reads under the same key), totals[1] += candidates past the OVERLAP_MIN
+//                 gate (= pairs the reference's loop tries if no run ever succeeded)
+// Before this form the scan wrote all 57 G candidates of a million reads (8 B each), a second pass fetched each with one
+// scattered 64-byte line of its query to do these 32 rows, and two more passes packed the 4 % worth keeping: scan + packing
+// + sort 2.57 s of a 5.4 s run; each false candidate now costs its share of one coalesced record line and ~9 instructions.
+template <bool HASHED>
+static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
+k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *surv_off, uint64_t *surv, uint32_t slice_cap,
+           uint32_t *needed, OvlCfg cfg, PreThresholds pre_t, unsigned long long *totals) {
+    PBA_OVL_RUN_LISTS(HASHED);
+    __shared__ uint32_t cursor, s_cand, s_ok;
+    const uint32_t tl = blockIdx.x, t = t_lo + tl;
+    const int lane = threadIdx.x & (PBA_WAVE - 1), w = threadIdx.x / PBA_WAVE;
+    if (threadIdx.x == 0) { cursor = 0; s_cand = 0; s_ok = 0; }
+    __syncthreads();
+    const int len = (int)Rd.len[t];
+    const uint8_t *seq = Rd.packed + Rd.off[t];
+    const PackedFetch tf = fetch_of(Rd, t, 0, 1);
+    const TargetWalk tw(len);
+    const HeadTail ht(len);
+    uint64_t *out = surv_off ? surv + surv_off[tl] : nullptr;
+    uint32_t ncand = 0, nok = 0;
+    const int steps = (tw.nchunks + PBA_WAVE * PBA_OVL_WAVES - 1) / (PBA_WAVE * PBA_OVL_WAVES);
+    for (int st = 0; st < steps; ++st) {
+        const int c = st * PBA_WAVE * PBA_OVL_WAVES + (int)threadIdx.x;
+        const bool live = c < tw.nchunks;
+        const uint64_t be = live ? chunk_bits(seq, (uint32_t)c) : 0ull;
+        PBA_OVL_LOOKUP16();
+#pragma unroll
+        for (int h0 = 0; h0 < PBA_OVL_PPT; h0 += PBA_OVL_HALF) {
+            PBA_OVL_COMPACT();
+            for (uint32_t slot0 = 0; slot0 < Tot; slot0 += PBA_WAVE) {
+                const uint32_t slot = slot0 + (uint32_t)lane;
+                const bool have = slot < Tot;
+                uint32_t lo_r = 0, hi_r = R;                             // last run with r_rel <= slot
+                while (hi_r - lo_r > 1) {
+                    const uint32_t mid = (lo_r + hi_r) >> 1;
+                    if (r_rel[w][mid] <= slot) lo_r = mid; else hi_r = mid;
+                }
+                const uint32_t e = r_s0[w][lo_r] + (have ? slot - r_rel[w][lo_r] : 0u);
+                const uint4 rec = T.prec[e];                             // (a lane without a slot reads its run's first record)
+                const uint32_t q = rec.x >> PBA_OVL_JD_BITS, jd = rec.x & ((1u << PBA_OVL_JD_BITS) - 1);
+                bool valid = have && q != t;
+                if (HASHED) valid = valid && T.pkey[e] == r_key[w][lo_r];
+                const int j = (int)(jd >> 1);
+                const bool fwd = (jd & 1u) == 0;
+                const int s_len = (int)rec.y - j;                        // spaced_seed.cpp:274-275: slen - j in both directions
+                const bool ok = valid && s_len >= cfg.overlap_min;       // spaced_seed.cpp:280
+                const uint32_t ord = r_ord[w][lo_r];
+                const int hit = ht.pos_of((int)ord);
+                const int r_off = fwd ? hit : hit + 15;                  // spaced_seed.cpp:285
+                const int r_len = fwd ? len - r_off : r_off + 1;         // ref_seq.h:284-285
+                AlnOut po;
+                int fr = 0;
+                if (prefilter32_applies(ok, r_len, s_len, cfg.R, 0, 0, po)) {
+                    uint32_t alo, ahi;
+                    load_planes32(tf.at(r_off, fwd ? 1 : -1), 0, alo, ahi);          // rows: the target from its hit
+                    fr = prefilter32_planes(alo, ahi, rec.z, rec.w, pre_t);          // columns: the probe's record
+                }
+                const bool survivor = ok && fr == 0;
+                ncand += valid; nok += ok;
+                const uint64_t sm = __builtin_amdgcn_ballot_w64(survivor);
+                if (sm) {
+                    // (every lane calls the atomic, lane 0 adds: tools/ubench_queue.hip)
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)atomicAdd(&cursor, lane == 0 ? (uint32_t)__builtin_popcountll(sm) : 0u));
+                    const uint32_t at = base + (uint32_t)__builtin_popcountll(sm & ((1ull << lane) - 1ull));
+                    if (survivor && out && at < slice_cap)
+                        out[at] = (uint64_t)q << PBA_OVL_Q_SHIFT | (uint64_t)jd << PBA_OVL_ORD_BITS | (uint64_t)ord;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                             // before the next round overwrites the lists
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < PBA_WAVE; d <<= 1) { ncand += __shfl_xor(ncand, d, PBA_WAVE); nok += __shfl_xor(nok, d, PBA_WAVE); }
+    if (lane == 0) { atomicAdd(&s_cand, ncand); atomicAdd(&s_ok, nok); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        needed[tl] = cursor;
+        atomicAdd(&totals[0], (unsigned long long)s_cand);
+        atomicAdd(&totals[1], (unsigned long long)s_ok);
+    }
 }
 
 // A target whose slice outgrows one LDS sort (a million reads put 57 000 candidates on a target) is cut into pieces of
@@ -399,13 +494,6 @@ k_ovl_items(const uint32_t *item_pre, const uint32_t *cand_off, uint32_t n_targe
 #define PBA_OVL_CHUNK 16          // work items a wavefront takes at a time (big inputs)
 #define PBA_OVL_S2_CAP 256        // survivors of the first prefilter stage a chunk can hand to the second
 
-struct OvlCfg {
-    double R;
-    int overlap_min;
-    int row_cap;      // u16 cells of LDS per wavefront
-    uint32_t t2;
-    uint32_t chunk;   // work items a wavefront of the walk takes at a time when there are >= 2^20 of them (0: PBA_OVL_CHUNK)
-};
 
 // One candidate of target `ref` (length ref_len, visiting order ht) set up like spaced_seed.cpp:274-286 /
 // ref_seq.h:282-286.  ok = false: skipped before the aligner (segment shorter than OVERLAP_MIN).
@@ -447,128 +535,6 @@ __device__ __forceinline__ void ovl_emit(pba_overlap *out, unsigned long long ca
     }
 }
 
-// ---- the first prefilter stage BEFORE the sort (big calls)
-// 98.6 % of the candidates fail their first 32 rows (prefilter.h), and all a failed candidate ever contributes is +1 to the
-// pair count -- unless its (target, query) run has a success before it, in which case the reference never tried it.  A run
-// with a success has a candidate that passes the prefilter.  So: k_ovl_pre runs the first stage over the UNSORTED slices
-// and sets, per target, a bit for the query of every candidate that passes (a Bloom filter with one hash: 2^10 .. 2^16 bits
-// per target); k_ovl_keep then keeps the candidates whose query has its bit set -- every run that can hold a success, whole
-// and therefore still in the reference's order once sorted, plus a few per cent of false positives -- and the rest, runs
-// in which every candidate failed its first 32 rows, are pairs the reference aligned and dropped: counted, not sorted, not
-// walked.  Sort and walk then see ~3-5 % of the list and do with it exactly what they did with all of it.
-// Candidates the walk would skip before the aligner (OvlCand::ok false) leave the list here (counted per target: they are
-// neither pairs nor kept).
-// bits per target: a power of two, about twice the candidates a target has on average (a thirtieth of them set a bit),
-// between 2^10 and 2^16 (a slot fits the 2-byte array of the packing passes; 0xFFFF = none)
-#define PBA_OVL_BLOOM_MIN_BITS 10
-#define PBA_OVL_BLOOM_MAX_BITS 16
-__device__ __forceinline__ uint32_t ovl_bloom_slot(uint32_t q, int bits) {
-    const uint32_t s = (q * 0x9E3779B1u) >> (32 - bits);
-    return s == 0xFFFFu ? 0xFFFEu : s;
-}
-
-// What the stage needs of a QUERY is its length and 32 bases next to one of its ends (a probe sits at offset j <= 31 from
-// the start, or from the end walking left): through the read set that is three scattered lines per candidate (length,
-// plane offset, plane words) -- at a million reads mostly from HBM.  The ends of every read are therefore put side by side
-// once per call: one 64-byte line per read, 64 MB at a million reads (Infinity-Cache resident), one line per candidate.
-struct __attribute__((aligned(32))) OvlEnd {
-    uint32_t len, pad;
-    uint64_t lo, hi;      // bit planes of 64 bases: [0] the first 64 (bit b = base b), [1] the last 64 (bit b = base len - 64 + b)
-};
-static __global__ void __launch_bounds__(256)
-k_ovl_ends(SeqSetDev Rd, uint32_t n, OvlEnd *ends) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const int len = (int)Rd.len[q];
-    const PackedFetch f = fetch_of(Rd, q, 0, 1);
-    OvlEnd h = {(uint32_t)len, 0u, 0ull, 0ull}, t = h;
-    if (len >= 64) {
-        uint32_t l0, h0, l1, h1;
-        load_planes32(f, 0, l0, h0); load_planes32(f, 32, l1, h1);
-        h.lo = (uint64_t)l1 << 32 | l0; h.hi = (uint64_t)h1 << 32 | h0;
-        load_planes32(f, len - 64, l0, h0); load_planes32(f, len - 32, l1, h1);
-        t.lo = (uint64_t)l1 << 32 | l0; t.hi = (uint64_t)h1 << 32 | h0;
-    }
-    ends[2 * (size_t)q] = h; ends[2 * (size_t)q + 1] = t;
-}
-
-// one wavefront per item = (target, 64 consecutive slots of its unsorted slice; cand_end[t] ends the slice)
-static __global__ void __launch_bounds__(256)
-k_ovl_pre(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, const uint32_t *cand_end, const uint64_t *cand, OvlCfg cfg,
-          PreThresholds pre_t, const OvlEnd *ends, uint32_t *bloom, int bloom_bits, uint32_t *n_blanked, uint16_t *slot_of) {
-    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
-    if (item >= n_items) return;
-    const uint2 it = items[item];
-    const uint32_t c = it.y + lane;
-    const uint64_t cd = c < cand_end[it.x] ? cand[c] : ~0ull;
-    const uint32_t t = t_lo + it.x;
-    const int ref_len = (int)Rd.len[t];
-    const HeadTail ht(ref_len);
-    const bool have = cd != ~0ull;
-    const uint64_t cdv = have ? cd : 0ull;
-    const bool bwd = (cdv >> PBA_OVL_ORD_BITS) & 1ull;
-    const OvlEnd er = ends[2 * (size_t)(uint32_t)(cdv >> PBA_OVL_Q_SHIFT) + (bwd ? 1 : 0)];
-    const OvlCand m = ovl_decode_len((int)er.len, ref_len, ht, cdv, cfg);
-    const bool blank = have && !m.ok;                 // (leaves the list through its slot: 0xFFFF below)
-    const uint64_t bm = __builtin_amdgcn_ballot_w64(blank);
-    if (bm) atomicAdd(&n_blanked[it.x], lane == 0 ? (uint32_t)__builtin_popcountll(bm) : 0u);
-    AlnOut po;
-    int fr = 0;
-    if (prefilter32_applies(have && m.ok, m.r_len, m.s_len, cfg.R, 0, 0, po)) {
-        uint32_t alo, ahi, blo, bhi;
-        load_planes32(fetch_of(Rd, t, m.r_off, m.fwd ? 1 : -1), 0, alo, ahi);           // rows: the target from its hit
-        if (er.len >= 64 && m.j <= 32) {                                                // columns: the query's 32 bases, from its end record
-            // forward: element r = base j + r = head bit j + r; backward: element r = base len - j - 1 - r = tail bit 63 - j - r
-            const int sh = m.fwd ? m.j : 32 - m.j;
-            blo = (uint32_t)(er.lo >> sh); bhi = (uint32_t)(er.hi >> sh);
-            if (!m.fwd) { blo = __builtin_bitreverse32(blo); bhi = __builtin_bitreverse32(bhi); }
-        } else load_planes32(fetch_of(Rd, m.q, m.s_off, m.fwd ? 1 : -1), 0, blo, bhi);
-        fr = prefilter32_planes(alo, ahi, blo, bhi, pre_t);
-    }
-    // the Bloom slot of every candidate still in the list (0xFFFF: none), so that the passes that pack the list read 2 bytes
-    // per candidate instead of 8
-    const uint32_t s = ovl_bloom_slot(m.q, bloom_bits);
-    if (c < cand_end[it.x]) slot_of[c] = have && m.ok ? (uint16_t)s : (uint16_t)0xFFFFu;
-    if (have && m.ok && fr == 0) atomicOr(&bloom[((size_t)it.x << (bloom_bits - 5)) + (s >> 5)], 1u << (s & 31u));
-}
-
-// same items: the candidates whose query has its bit set are packed densely, target after target, into a second buffer (in
-// any order inside a target: they are sorted next).  Count per item, prefix sums over the items (k_scan_*), write -- a
-// cursor per target moved with atomics instead had every wavefront of the chip on the same few words (the items of a
-// target run together): 84 s of a 7.9 s run at a million reads.
-__device__ __forceinline__ bool ovl_kept(const uint32_t *bloom, int bloom_bits, uint32_t tl, uint32_t s) {
-    return s != 0xFFFFu && ((bloom[((size_t)tl << (bloom_bits - 5)) + (s >> 5)] >> (s & 31u)) & 1u);
-}
-// kept_of[item] = candidates of the item that stay
-static __global__ void __launch_bounds__(256)
-k_ovl_keep_count(uint32_t n_items, const uint2 *items, const uint32_t *cand_end, const uint16_t *slot_of, const uint32_t *bloom,
-                 int bloom_bits, uint32_t *kept_of) {
-    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
-    if (item >= n_items) return;
-    const uint2 it = items[item];
-    const uint32_t c = it.y + lane;
-    const uint64_t km = __builtin_amdgcn_ballot_w64(ovl_kept(bloom, bloom_bits, it.x, c < cand_end[it.x] ? slot_of[c] : 0xFFFFu));
-    if (lane == 0) kept_of[item] = (uint32_t)__builtin_popcountll(km);
-}
-// kept_before[item] = candidates kept by the items before it (kept_before[n_items] = all of them)
-static __global__ void __launch_bounds__(256)
-k_ovl_keep_write(uint32_t n_items, const uint2 *items, const uint32_t *cand_end, const uint64_t *cand, const uint16_t *slot_of,
-                 const uint32_t *bloom, int bloom_bits, const uint32_t *kept_before, uint64_t *kept) {
-    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), item = blockIdx.x * (blockDim.x / PBA_WAVE) + threadIdx.x / PBA_WAVE;
-    if (item >= n_items) return;
-    const uint2 it = items[item];
-    const uint32_t c = it.y + lane;
-    const bool keep = ovl_kept(bloom, bloom_bits, it.x, c < cand_end[it.x] ? slot_of[c] : 0xFFFFu);
-    const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
-    if (keep) kept[kept_before[item] + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = cand[c];
-}
-// where every target's kept candidates start in the packed list: the prefix sum at its first item
-static __global__ void __launch_bounds__(256)
-k_ovl_keep_offsets(const uint32_t *item_pre, const uint32_t *kept_before, uint32_t n_targets, uint32_t *kept_off) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t <= n_targets) kept_off[t] = kept_before[item_pre[t]];
-}
-
 // First launch (redo_in == nullptr): persistent wavefronts pull work items = (target, group of 64 consecutive
 // candidates) and walk them with the narrow window (NB = 0: row sweep).  Candidates of one (target, query) are
 // consecutive and must be tried in order, so a group owns the runs that START in it: it skips a leading run begun in
@@ -606,7 +572,10 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
     __shared__ uint32_t s2_fail[WPB][PBA_OVL_CHUNK][2];
     __shared__ uint16_t s2_list[WPB][PBA_OVL_S2_CAP];
     __shared__ uint64_t s_cd[WPB][PBA_WAVE];           // the group in flight: kept here, not in registers, while the array has the wavefront
-    const bool two_stage = NB != 0 && !redo_in;
+    // cfg.fused: every listed candidate has passed its first 32 rows in the scan (k_ovl_scan), which also counted the pairs;
+    // a chunk then goes through rows 33..64 directly (no first stage, no survivor list) and nothing is counted here
+    const bool fused = NB != 0 && cfg.fused != 0;
+    const bool two_stage = NB != 0 && !redo_in && !fused;
     unsigned long long pairs = 0;
     for (;;) {
         const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
@@ -614,6 +583,23 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
         if (base >= n_items) break;
         const uint32_t item_end = min(n_items, base + chunk);
         if constexpr (NB != 0) {
+          if (fused && !redo_in) {
+            for (uint32_t k = 0; k < item_end - base; ++k) {
+                const uint2 it = items[base + k];
+                const uint32_t c_end_k = cand_off[it.x] + cand_cnt[it.x];
+                const bool act = lane_id < min((uint32_t)PBA_WAVE, c_end_k - it.y);
+                const uint64_t cd = act ? cand[it.y + lane_id] : 0ull;
+                const uint32_t t = t_lo + it.x;
+                const int ref_len = (int)Rd.len[t];
+                const HeadTail ht(ref_len);
+                const OvlCand m = ovl_decode(Rd, ref_len, ht, cd, cfg);
+                const bool fail2 = prefilter64(act && m.ok, fetch_of(Rd, t, m.r_off, m.fwd ? 1 : -1), m.r_len,
+                                               fetch_of(Rd, act ? m.q : 0u, m.s_off, m.fwd ? 1 : -1), m.s_len, cfg.R);
+                const uint64_t f2 = __builtin_amdgcn_ballot_w64(fail2);
+                if (l0) { s2_fail[wave][k][0] = (uint32_t)f2; s2_fail[wave][k][1] = (uint32_t)(f2 >> 32); }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
           if (two_stage) {
             uint32_t ns = 0;                                            // survivors of stage 1 listed so far (wave-uniform)
             for (uint32_t k = 0; k < item_end - base; ++k) {
@@ -688,9 +674,11 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
             const OvlCand m = ovl_decode(Rd, ref_len, ht, mycd, cfg);
             int myfr = 0;
             if constexpr (NB != 0) {
-                if (two_stage && c0 == c_begin) {                        // both stages ran on this group with the rest of the chunk
+                if ((two_stage || (fused && !redo_in)) && c0 == c_begin) {   // the stage(s) ran on this group with the rest of the chunk
                     const uint32_t w32 = s2_fail[wave][item - base][lane >> 5];
                     myfr = (int)((w32 >> (lane & 31u)) & 1u);
+                } else if (fused) {
+                    myfr = 0;                                            // passed its first 32 rows in the scan: the array decides
                 } else {
                     AlnOut po;
                     myfr = prefilter32(act && m.ok, ref.at(m.r_off, m.fwd ? 1 : -1), m.r_len,
@@ -754,6 +742,73 @@ k_ovl_walk(SeqSetDev Rd, uint32_t t_lo, uint32_t n_items, const uint2 *items, co
         }
     }
     atomicAdd(n_pairs, l0 ? pairs : 0ull);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// What a success spares.  The reference walks a (target, query) run in order and stops at the first success
+// (spaced_seed.cpp:424-432, 288-297): the run's candidates behind it are never handed to align().  The scan has counted
+// every candidate past the OVERLAP_MIN gate as a pair (k_ovl_scan: totals[1]); this kernel takes one wavefront per reported
+// overlap (target t, query q, probe jd* = 2j + backward, hit position -> ordinal ord*) and counts the candidates of the run
+// that sort behind (jd*, ord*): for every probe jd > jd* of q that exists (spaced_seed.cpp:426, key != 0) and passes the gate,
+// the visited positions of t with the same masked key, plus the positions behind ord* under the success's own key.
+// pairs = totals[1] - sum over the overlaps.  (~10 k instructions per success, against ~700 k for the alignment itself.)
+#define PBA_OVL_AFTER_SLOTS 512                    // hash slots per wavefront for <= 126 probe keys
+static __global__ void __launch_bounds__(PBA_WAVE * 4)
+k_ovl_after(SeqSetDev Rd, const pba_overlap *ov, uint32_t n_ov, uint32_t mask, uint32_t t2, int overlap_min, unsigned long long *after) {
+    __shared__ uint32_t h_key[4][PBA_OVL_AFTER_SLOTS], h_cnt[4][PBA_OVL_AFTER_SLOTS];
+    const uint32_t lane = threadIdx.x & (PBA_WAVE - 1), wave = threadIdx.x / PBA_WAVE;
+    const uint32_t i = blockIdx.x * 4 + wave;
+    if (i >= n_ov) return;                                               // (wave-uniform; no workgroup barrier below)
+    const pba_overlap o = ov[i];
+    const uint32_t t = (uint32_t)o.target, q = (uint32_t)o.query;
+    const uint32_t jd0 = 2u * (uint32_t)o.j + (o.dir < 0 ? 1u : 0u);
+    const int tlen = (int)Rd.len[t], slen = (int)Rd.len[q];
+    const TargetWalk tw(tlen);
+    const int ord0 = tw.ord_of(o.ref_pos);
+    const uint8_t *tseq = Rd.packed + Rd.off[t], *qseq = Rd.packed + Rd.off[q];
+    for (uint32_t k = lane; k < PBA_OVL_AFTER_SLOTS; k += PBA_WAVE) { h_key[wave][k] = 0u; h_cnt[wave][k] = 0u; }   // key 0 = empty: no probe has it
+    __builtin_amdgcn_wave_barrier();
+    // the probes of q from jd* on: the success's own key, and the later ones into the table with their multiplicity
+    uint32_t key0 = 0;
+    for (uint32_t jb = 0; jb < t2; jb += PBA_WAVE) {
+        const uint32_t jd = jb + lane;
+        const int j = (int)(jd >> 1);
+        const int pos = (jd & 1u) ? slen - j - 16 : j;                   // spaced_seed.cpp:426
+        const bool exists = jd < t2 && jd >= jd0 && pos >= 0 && pos + 16 <= slen && slen - j >= overlap_min;
+        const uint32_t key = exists ? window_key(qseq, (uint32_t)pos, (uint32_t)slen) & mask : 0u;
+        const uint64_t own = __builtin_amdgcn_ballot_w64(jd == jd0);
+        if (own) key0 = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(own));
+        if (key != 0u && jd != jd0) {
+            uint32_t h = (key * 0x9E3779B1u) >> (32 - 9);
+            for (;;) {
+                const uint32_t old = atomicCAS(&h_key[wave][h], 0u, key);
+                if (old == 0u || old == key) { atomicAdd(&h_cnt[wave][h], 1u); break; }
+                h = (h + 1) & (PBA_OVL_AFTER_SLOTS - 1);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t cnt = 0;
+    for (int c = (int)lane; c < tw.nchunks; c += PBA_WAVE) {
+        const uint64_t be = chunk_bits(tseq, (uint32_t)c);
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t key = __builtin_bswap32((uint32_t)((be << (2 * k)) >> 32)) & mask;
+            const int ord = tw.ord_of(16 * c + k);
+            if (key == 0u || ord < 0) continue;                          // ref_seq.h:300,307
+            if (key == key0 && ord > ord0) ++cnt;
+            uint32_t h = (key * 0x9E3779B1u) >> (32 - 9);
+            for (;;) {
+                const uint32_t kk = h_key[wave][h];
+                if (kk == 0u) break;
+                if (kk == key) { cnt += h_cnt[wave][h]; break; }
+                h = (h + 1) & (PBA_OVL_AFTER_SLOTS - 1);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < PBA_WAVE; d <<= 1) cnt += __shfl_xor(cnt, d, PBA_WAVE);
+    if (lane == 0 && cnt) atomicAdd(after, (unsigned long long)cnt);
 }
 
 #endif

@@ -22,7 +22,7 @@ extern "C" {
                        items, d_woff, d_wcnt, d_cand.as<uint64_t>(), ocfg, full_band,                                    \
                        redo_in, d_redo.as<uint2>(),                                                                      \
                        (unsigned long long)redo_cap, d_cnt64.as<unsigned long long>() + 2, d_out.as<pba_overlap>(),     \
-                       (unsigned long long)cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1,  \
+                       (unsigned long long)dev_cap, d_cnt64.as<unsigned long long>(), d_cnt64.as<unsigned long long>() + 1, \
                        ctx->d_queue)
 
 // the probe table of a read set (overlap.h: ProbeTab), built once and scanned by every target range
@@ -33,6 +33,7 @@ struct pba_probe_table {
     uint32_t t2;
     uint64_t n_entries;
     float build_ms;
+    mutable const pba_seqs *rec_reads;   // the read set prec[] was filled from (nullptr: not yet -- on first use, overlap.h: k_pt_ctx)
     // what a call learned from its sample about this read set under (R, ring): whether the narrow window certifies its
     // overlaps.  The next target ranges against the same table skip the sample (three launches and their tails per call).
     mutable uint32_t slice_max;    // largest / average candidate slice of a target in the last counted range of >= 1 024 targets (0: none yet)
@@ -104,7 +105,7 @@ void pba_probe_table_destroy(pba_probe_table *t) {
     if (t->T.pid) (void)hipFree(t->T.pid);
     if (t->T.pkey) (void)hipFree(t->T.pkey);
     if (t->T.presence) (void)hipFree(t->T.presence);
-    if (t->T.rec) (void)hipFree(t->T.rec);
+    if (t->T.prec) (void)hipFree(t->T.prec);
     delete t;
 }
 
@@ -170,9 +171,6 @@ int pba_probe_table_create(pba_ctx *ctx, const void *d_probe_entries, uint64_t n
         if (t->hashed) hipLaunchKernelGGL(k_pt_fill<true>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T, d_cursor.as<uint32_t>(), t->t2);
         else hipLaunchKernelGGL(k_pt_fill<false>, dim3(grid), dim3(256), 0, ctx->stream, ent, n, T, d_cursor.as<uint32_t>(), t->t2);
     }
-    HIPCHK(hipMalloc((void **)&T.rec, sizeof(uint2) * (B + 2)));
-    HIPCHK(hipMemsetAsync(T.rec + B, 0, sizeof(uint2) * 2, ctx->stream));
-    hipLaunchKernelGGL(k_pt_pack, dim3((uint32_t)((B + 1 + 255) / 256)), dim3(256), 0, ctx->stream, T, B + 1, total);
     (void)hipEventRecord(ctx->ev[1], ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipGetLastError());
@@ -202,185 +200,153 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     int rc = make_plan(ctx, R, 0, 0, kernel, 1 + (int)(reads->max_len * R), &pl);
     if (rc != PBA_OK) return rc;
     const ProbeTab &T = tab->T;
-    DevBuf d_cnt64;
-    HIPCHK(hipMalloc(&d_cnt64.p, 32));
+    DevBuf d_cnt64;                // [0] overlaps, [1] pairs (the row-sweep form's walk), [2] parked runs; [4] seed matches, [5] candidates
+    HIPCHK(hipMalloc(&d_cnt64.p, 64));   // past the gate (k_ovl_scan), [6] candidates behind a success (k_ovl_after)
+    HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 64, ctx->stream));
+    const bool fused = pl.nb1 != 0;          // the bit-vector kernels: first 32 rows in the scan, survivors only in memory
 
-    // 1. count: the slice of the candidate array every target needs -- or, for a later range of a table whose slices are
-    //    known to be big and even (capacity mode), no count pass: every target gets the same room, 1.25 x the largest slice
-    //    seen, and the fill pass reports what it needed; a target that outgrows its room sends the range through the
-    //    counted way after all.  Capacity mode leaves gaps in the candidate array, which only the pre-sort stage (2b) can
-    //    read, so it implies that stage.
     BufRef d_slice, d_off, d_valid, d_cand, d_tmp, d_out, d_small;
-    // (the big arrays of a call live in the ctx's pool: at a million reads a target range needs 11 GB of candidates twice,
-    // and mapping those anew for each of the 40 ranges took longer than everything the kernels do)
+    // (the big arrays of a call live in the ctx's pool: mapping gigabytes anew for each target range of a table took longer
+    // than everything the kernels do)
     POOL(POOL_OVL_SMALL, sizeof(uint32_t) * 5 * ((size_t)nt + 1), d_small.p);
     d_slice.p = d_small.as<uint32_t>(); d_off.p = d_small.as<uint32_t>() + (nt + 1); d_valid.p = d_small.as<uint32_t>() + 2 * ((size_t)nt + 1);
-    uint32_t *const d_end = d_small.as<uint32_t>() + 4 * ((size_t)nt + 1);       // where every target's slice ends
-    std::vector<uint32_t> h_slice(nt + 1), h_off(nt + 1), h_valid(nt + 1), h_end(nt + 1);
-    uint64_t total = 0, extent = 0, max_cand = PBA_OVL_MAX_CANDIDATES;
+    std::vector<uint32_t> h_slice(nt + 1), h_off(nt + 1), h_valid(nt + 1);
+    uint64_t total = 0, max_cand = PBA_OVL_MAX_CANDIDATES;
     if (const char *e = getenv("PBA_OVL_MAX_CANDIDATES")) max_cand = std::min<uint64_t>(max_cand, (uint64_t)atoll(e));   // test hook: the limit at test sizes
-    uint64_t prekeep_min = 1ull << 29;                           // (2b)
-    if (const char *e = getenv("PBA_OVL_PREKEEP_MIN")) prekeep_min = (uint64_t)std::max(0LL, atoll(e));   // test hook: small inputs through the stage (or none)
-    uint32_t slice_cap = 0;
-    if (pl.nb1 != 0 && tab->slice_max > 0) {
-        int pct = 125;
-        if (const char *e = getenv("PBA_OVL_CAPFILL_PCT")) pct = atoi(e);         // test hook: 0 = never, small = overflow and fall back
-        const uint64_t c = (uint64_t)tab->slice_max * (uint64_t)std::max(0, pct) / 100 + (pct > 0 ? 64 : 0);
-        if (pct > 0 && (uint64_t)(tab->slice_avg * nt) >= prekeep_min && c * nt < max_cand && c < 0xFFFFFFFFull) slice_cap = (uint32_t)c;
-    }
     uint32_t biggest_small = 2;
-    std::vector<uint32_t> big;                                   // targets whose slice outgrows one LDS sort
-    bool cap_mode = false;
+    std::vector<uint32_t> big;                                   // row-sweep form: targets whose slice outgrows one LDS sort
+    OvlCfg ocfg;
+    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2; ocfg.chunk = fused ? 1u : 0u; ocfg.fused = fused ? 1 : 0;
+    uint64_t n_cand = 0, n_ok = 0;
     (void)hipEventRecord(ctx->ev[2], ctx->stream);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        cap_mode = attempt == 0 && slice_cap != 0;
-        if (attempt == 0 && !cap_mode) continue;
-        total = 0;
-        if (cap_mode) {
-            for (uint32_t i = 0; i <= nt; ++i) h_off[i] = (uint32_t)((uint64_t)i * slice_cap);
-            extent = (uint64_t)nt * slice_cap;
-        } else {
-            if (tab->hashed) hipLaunchKernelGGL(k_ovl_count<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
-            else hipLaunchKernelGGL(k_ovl_count<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+    if (fused) {
+        // 1. the records of the probe table from this read set, once per table
+        if (tab->rec_reads != reads) {
+            if (!T.prec) HIPCHK(hipMalloc((void **)&const_cast<ProbeTab &>(T).prec, sizeof(uint4) * ((uint64_t)tab->n_entries + 1)));
+            if (tab->n_entries)
+                hipLaunchKernelGGL(k_pt_ctx, dim3((uint32_t)((tab->n_entries + 255) / 256)), dim3(256), 0, ctx->stream, T, reads->dev(),
+                                   (uint32_t)tab->n_entries);
+            HIPCHK(hipGetLastError());
+            tab->rec_reads = reads;
+        }
+        // 2. the scan.  How much room a target's survivors need is not known before its candidates have been through their
+        //    32 rows: the first range of a table runs the scan once without writing (needed[] only) and then with exact
+        //    slices; later ranges give every target the same room -- 1.25 x the largest need seen, + 64 -- and fall back to
+        //    exact slices (needed[] of the clipped run) when a target outgrows it.
+        uint32_t room = 0;
+        if (tab->slice_max > 0) {
+            int pct = 125;
+            if (const char *e = getenv("PBA_OVL_CAPFILL_PCT")) pct = atoi(e);     // test hook: 0 = never, small = overflow and fall back
+            const uint64_t c = (uint64_t)tab->slice_max * (uint64_t)std::max(0, pct) / 100 + 64;
+            if (pct > 0 && c * nt < max_cand) room = (uint32_t)c;
+        }
+        if (room == 0)
+            if (const char *e = getenv("PBA_OVL_ROOM")) room = (uint32_t)std::max(0, atoi(e));   // test hook: equal room (and its overflow path) in a table's first range
+        const PreThresholds pre_t = PreThresholds::on_host(R);
+        auto scan = [&](bool write, uint32_t cap_slots) -> int {
+            HIPCHK(hipMemsetAsync(d_cnt64.as<unsigned long long>() + 4, 0, 16, ctx->stream));
+            const uint32_t *so = write ? d_off.as<uint32_t>() : nullptr;
+            if (tab->hashed) hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
+            else hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
+            HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            HIPCHK(hipGetLastError());
-            uint32_t mx = 0;
-            for (uint32_t i = 0; i < nt; ++i) {
-                h_off[i] = (uint32_t)total;
-                total += h_slice[i];
-                mx = std::max(mx, h_slice[i]);
-                if (total >= max_cand) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
-                if (h_slice[i] <= PBA_IX_LDS_SORT_CAP) biggest_small = std::max(biggest_small, h_slice[i]);
-                else big.push_back(i);
-            }
-            h_off[nt] = (uint32_t)total;
-            extent = total;
-            if (nt >= 1024) { tab->slice_max = mx; tab->slice_avg = (double)total / nt; }   // what a later range goes by
+            return PBA_OK;
+        };
+        bool have_exact = false;
+        if (room == 0) {
+            rc = scan(false, 0);                                 // census
+            if (rc != PBA_OK) return rc;
+            have_exact = true;
         }
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            uint64_t extent = 0;
+            if (have_exact) {
+                uint32_t mx = 0;
+                for (uint32_t i = 0; i < nt; ++i) {
+                    h_off[i] = (uint32_t)extent; extent += h_slice[i]; mx = std::max(mx, h_slice[i]);
+                    if (extent >= max_cand) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
+                }
+                if (nt >= 1024 || tab->slice_max == 0) { tab->slice_max = std::max(mx, 1u); tab->slice_avg = (double)extent / nt; }   // what a later range goes by
+            } else {
+                for (uint32_t i = 0; i < nt; ++i) h_off[i] = (uint32_t)((uint64_t)i * room);
+                extent = (uint64_t)nt * room;
+            }
+            h_off[nt] = (uint32_t)extent;
+            HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
+            POOL(POOL_OVL_CAND, sizeof(uint64_t) * (extent + 1), d_cand.p);
+            rc = scan(true, have_exact ? 0xFFFFFFFFu : room);
+            if (rc != PBA_OK) return rc;
+            if (have_exact) break;
+            bool over = false;
+            for (uint32_t i = 0; i < nt; ++i) over = over || h_slice[i] > room;
+            if (!over) { st.cap_fill = 1; break; }
+            st.cap_overflow = 1;                                 // a target outgrew its room: once more, with what each one needed
+            have_exact = true;
+        }
+        unsigned long long h_tot[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(h_tot, d_cnt64.as<unsigned long long>() + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        n_cand = h_tot[0]; n_ok = h_tot[1];
+        for (uint32_t i = 0; i < nt; ++i) { h_valid[i] = h_slice[i]; total += h_slice[i]; }
+        HIPCHK(hipMemcpyAsync(d_valid.p, h_valid.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, ctx->stream));
+        st.n_prefiltered = n_ok - total;
+    } else {
+        // 1. count: the slice of the candidate array every target needs
+        if (tab->hashed) hipLaunchKernelGGL(k_ovl_count<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+        else hipLaunchKernelGGL(k_ovl_count<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_slice.as<uint32_t>());
+        HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        for (uint32_t i = 0; i < nt; ++i) {
+            h_off[i] = (uint32_t)total;
+            total += h_slice[i];
+            if (total >= max_cand) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: 2^32 candidates or more in one target range; use smaller ranges");
+            if (h_slice[i] <= PBA_IX_LDS_SORT_CAP) biggest_small = std::max(biggest_small, h_slice[i]);
+            else big.push_back(i);
+        }
+        h_off[nt] = (uint32_t)total;
         HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-        POOL(POOL_OVL_CAND, sizeof(uint64_t) * (extent + 1), d_cand.p);
-
+        POOL(POOL_OVL_CAND, sizeof(uint64_t) * (total + 1), d_cand.p);
         // 2. fill: the candidates (all-ones where a slot belongs to the target's own probe or to another key)
-        if (extent) {
-            uint32_t *const d_written = cap_mode ? d_slice.as<uint32_t>() : nullptr;
-            // runs of >= 6 probes on average: emit cooperatively (overlap.h).  Measured, second passes: a million reads (3.8
-            // per run) scan 0.88 s one run per lane / 0.91 s cooperatively; two million (7.6 per run) 3.41 / 3.12 s; four
-            // million (15 per run) 16.3 / 11.4 s
-            uint32_t coop_avg = 6;
-            if (const char *e = getenv("PBA_OVL_COOP_AVG")) coop_avg = (uint32_t)std::max(0, atoi(e));   // test hook: 0 = always
-            if (tab->hashed) hipLaunchKernelGGL(k_ovl_fill<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>(), cap_mode ? slice_cap : 0u, d_written, coop_avg);
-            else hipLaunchKernelGGL(k_ovl_fill<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>(), cap_mode ? slice_cap : 0u, d_written, coop_avg);
+        if (total) {
+            if (tab->hashed) hipLaunchKernelGGL(k_ovl_fill<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>());
+            else hipLaunchKernelGGL(k_ovl_fill<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, d_off.as<uint32_t>(), d_cand.as<uint64_t>(), d_valid.as<uint32_t>());
             HIPCHK(hipMemcpyAsync(h_valid.data(), d_valid.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
-            if (cap_mode) HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
         } else {
             HIPCHK(hipMemsetAsync(d_valid.p, 0, sizeof(uint32_t) * (nt + 1), ctx->stream));
         }
-        if (cap_mode) {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            HIPCHK(hipGetLastError());
-            bool over = false;
-            for (uint32_t i = 0; i < nt; ++i) { over = over || h_slice[i] > slice_cap; total += h_slice[i]; }
-            if (over) { st.cap_overflow = 1; continue; }         // a slice outgrew its room: once more, counted
-        }
-        break;
     }
     (void)hipEventRecord(ctx->ev[3], ctx->stream);
 
-    // 2b. big calls (>= 2^29 candidates) on the bit-vector kernels: the first prefilter stage before the sort (overlap.h: k_ovl_pre / k_ovl_keep).
-    //     What is kept goes packed into the second buffer; the sort below moves it back, sorted; everything after sees the
-    //     packed list (h_koff / h_kept) where it saw the slices (h_off / h_valid).  The time is the sort's in the statistics.
-    // (measured, calls of 50 000 targets: 23 M candidates 0.081 s with the stage / 0.065 s without -- the few thousand dense
-    // items that are left balance badly over 8 192 wavefronts --, 143 M 0.157 / 0.151, 573 M 0.333 / 0.330, 2.3 G 0.718 / 0.743,
-    // 9.2 G 1.68 / 1.99, 57 G 5.8 / 7.9: prekeep_min = 2^29, above)
-    const bool prekeep = total > 0 && (cap_mode || (pl.nb1 != 0 && total >= prekeep_min));
-    st.cap_fill = cap_mode ? 1 : 0;
-    for (uint32_t i = 0; i < nt; ++i) h_end[i] = h_off[i] + h_slice[i];
-    HIPCHK(hipMemcpyAsync(d_end, h_end.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, ctx->stream));
-    OvlCfg ocfg;
-    ocfg.R = R; ocfg.overlap_min = overlap_min; ocfg.row_cap = pl.cfg.row_cap; ocfg.t2 = t2; ocfg.chunk = prekeep ? 1u : 0u;
-    std::vector<uint32_t> h_kept, h_koff;                        // per target: candidates kept, and where they start in the packed list
-    uint32_t *d_koff = nullptr;
-    uint64_t n_dropped = 0;
-    BufRef d_items;
-    if (prekeep) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));               // h_valid
-        std::vector<uint32_t> h_ipre1(nt + 1);
-        uint64_t n_it = 0;
-        for (uint32_t i = 0; i < nt; ++i) { h_ipre1[i] = (uint32_t)n_it; n_it += (h_slice[i] + PBA_WAVE - 1) / PBA_WAVE; }
-        if (n_it >= 0xFFFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "pba_overlap_all: too many work items per call, use a smaller target range");
-        h_ipre1[nt] = (uint32_t)n_it;
-        uint32_t *d_ipre1 = d_small.as<uint32_t>() + 3 * ((size_t)nt + 1);
-        HIPCHK(hipMemcpyAsync(d_ipre1, h_ipre1.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
-        POOL(POOL_OVL_ITEMS, sizeof(uint2) * (n_it + 1), d_items.p);
-        hipLaunchKernelGGL(k_ovl_items, dim3((uint32_t)((n_it + 255) / 256)), dim3(256), 0, ctx->stream, d_ipre1, d_off.as<uint32_t>(), nt,
-                           (uint32_t)n_it, d_items.as<uint2>());
-        // per target: the Bloom words, its blanked count; per item: the kept counts (+1: exclusive prefix sums); per target + 1:
-        // the offsets into the packed list
-        BufRef d_bloom;
-        int bloom_bits = PBA_OVL_BLOOM_MIN_BITS;                 // ~2 x the average candidates of a target, a power of two
-        while (bloom_bits < PBA_OVL_BLOOM_MAX_BITS && (1ull << bloom_bits) < 2 * (total / nt)) ++bloom_bits;
-        const size_t bloom_words = (size_t)nt << (bloom_bits - 5);
-        const uint32_t n_tiles = (uint32_t)((n_it + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
-        POOL(POOL_OVL_BLOOM, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + n_it + 1 + n_tiles) + sizeof(uint16_t) * (extent + 2), d_bloom.p);
-        HIPCHK(hipMemsetAsync(d_bloom.p, 0, sizeof(uint32_t) * (bloom_words + 2 * ((size_t)nt + 1) + 1), ctx->stream));
-        uint32_t *const d_blanked = d_bloom.as<uint32_t>() + bloom_words;
-        d_koff = d_blanked + (nt + 1);
-        uint32_t *const d_before = d_koff + (nt + 1);            // [n_it + 1], [0] = 0 (the memset above reaches it)
-        uint32_t *const d_tiles = d_before + n_it + 1;
-        uint16_t *const d_slot = (uint16_t *)(d_tiles + n_tiles);    // [total]: the Bloom slot of every candidate
-        POOL(POOL_OVL_TMP, sizeof(uint64_t) * (total + 1), d_tmp.p);
-        BufRef d_ends;                                           // the ends of every read side by side (overlap.h: OvlEnd)
-        POOL(POOL_OVL_ENDS, sizeof(OvlEnd) * 2 * (size_t)n, d_ends.p);
-        hipLaunchKernelGGL(k_ovl_ends, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reads->dev(), n, d_ends.as<OvlEnd>());
-        const uint32_t g = (uint32_t)((n_it + 3) / 4);
-        hipLaunchKernelGGL(k_ovl_pre, dim3(g), dim3(256), 0, ctx->stream, reads->dev(), t_lo, (uint32_t)n_it, d_items.as<uint2>(),
-                           d_end, d_cand.as<uint64_t>(), ocfg, PreThresholds::on_host(R), d_ends.as<OvlEnd>(), d_bloom.as<uint32_t>(), bloom_bits, d_blanked, d_slot);
-        hipLaunchKernelGGL(k_ovl_keep_count, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_end,
-                           d_slot, d_bloom.as<uint32_t>(), bloom_bits, d_before + 1);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, d_tiles, n_tiles);
-        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, d_before + 1, n_it, d_tiles);
-        hipLaunchKernelGGL(k_ovl_keep_write, dim3(g), dim3(256), 0, ctx->stream, (uint32_t)n_it, d_items.as<uint2>(), d_end,
-                           d_cand.as<uint64_t>(), d_slot, d_bloom.as<uint32_t>(), bloom_bits, d_before, d_tmp.as<uint64_t>());
-        hipLaunchKernelGGL(k_ovl_keep_offsets, dim3((nt + 256) / 256), dim3(256), 0, ctx->stream, d_ipre1, d_before, nt, d_koff);
-        h_koff.resize(nt + 1);
-        std::vector<uint32_t> h_blanked(nt + 1);
-        HIPCHK(hipMemcpyAsync(h_koff.data(), d_koff, sizeof(uint32_t) * (nt + 1), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(h_blanked.data(), d_blanked, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipGetLastError());
-        h_kept.resize(nt + 1);
-        for (uint32_t i = 0; i < nt; ++i) {
-            h_kept[i] = h_koff[i + 1] - h_koff[i];
-            n_dropped += (uint64_t)h_valid[i] - h_blanked[i] - h_kept[i];
-        }
-        st.n_prefiltered = n_dropped;
-    }
-
     // 3. sort every target's slice = the reference's try order inside every (target, query): in LDS, in place; the big
-    //    ones piece by piece through a second buffer
+    //    ones (row-sweep form only: a million reads leave ~1 000 survivors per target, not 57 000 candidates) piece by piece
+    //    through a second buffer
     if (total) {
         // k_seg_sort (seed_index.h): buckets by query range, every bucket sorted in wavefront registers.  What it reports
-        // back (a slice with one bucket beyond 256 entries: one query with hundreds of candidates on the target) goes
-        // through the global bitonic pass.
+        // back (a slice with one bucket beyond 256 entries: one query with hundreds of candidates on the target; a slice
+        // beyond one workgroup) goes through the global bitonic pass.
         const uint32_t ov_cap = 4096;
         DevBuf d_ov;
         HIPCHK(hipMalloc(&d_ov.p, sizeof(uint32_t) * (1 + ov_cap) * 2));
         uint32_t *const ov_small = d_ov.as<uint32_t>(), *const ov_piece = ov_small + 1 + ov_cap;
         HIPCHK(hipMemsetAsync(d_ov.p, 0, sizeof(uint32_t) * (1 + ov_cap) * 2, ctx->stream));
         std::vector<SegRef> h_pieces;
-        if (prekeep) {
-            // the packed list, target after target, from the second buffer into the candidate array, sorted; a target that kept
-            // more than one sort holds (tandem repeats) is copied by the kernel and listed for the global pass
+        if (fused) {
+            // (equal-room slices have gaps: the segments are given one by one)
+            std::vector<SegRef> h_seg(nt);
             uint32_t biggest = 2;
-            for (uint32_t i = 0; i < nt; ++i) biggest = std::max(biggest, h_kept[i]);
-            launch_seg_sort(ctx, d_tmp.as<uint64_t>(), d_cand.as<uint64_t>(), d_koff, nullptr, nt,
+            for (uint32_t i = 0; i < nt; ++i) { h_seg[i] = SegRef{h_off[i], h_valid[i]}; biggest = std::max(biggest, h_valid[i]); }
+            BufRef d_seg;
+            POOL(POOL_OVL_TMP, sizeof(SegRef) * ((size_t)nt + 1), d_seg.p);
+            HIPCHK(hipMemcpyAsync(d_seg.p, h_seg.data(), sizeof(SegRef) * nt, hipMemcpyHostToDevice, ctx->stream));
+            launch_seg_sort(ctx, d_cand.as<uint64_t>(), d_cand.as<uint64_t>(), nullptr, d_seg.as<SegRef>(), nt,
                             std::min<uint32_t>(biggest, PBA_IX_LDS_SORT_CAP), seg_bkt_range(), ov_small, ov_cap);
+            HIPCHK(hipStreamSynchronize(ctx->stream));           // h_seg
         } else
         launch_seg_sort(ctx, d_cand.as<uint64_t>(), d_cand.as<uint64_t>(), d_off.as<uint32_t>(), nullptr, nt,
                         big.empty() ? biggest_small : 0xFFFFFFFFu, seg_bkt_range(), ov_small, ov_cap);
-        if (!prekeep && !big.empty()) {
+        if (!fused && !big.empty()) {
             st.n_big_targets = (uint32_t)big.size();
             DevBuf d_big, d_pieces, d_pc;
             const uint32_t sub_mul = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, ((uint64_t)PBA_OVL_SUB << 32) / n);   // fine bucket = umulhi(q, sub_mul)
@@ -417,10 +383,9 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
             v.erase(std::unique(v.begin(), v.end()), v.end());
             return v;
         };
-        for (uint32_t i : listed(h_ov.data(), nt))                    // small slices with an overfull bucket (the big ones are cut into pieces)
-            if (prekeep ? h_kept[i] > 1 : (h_slice[i] > 1 && h_slice[i] <= PBA_IX_LDS_SORT_CAP)) {
-                rc = prekeep ? sort_partition_global(ctx, d_cand.as<uint64_t>() + h_koff[i], h_kept[i])
-                             : sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], h_slice[i]);
+        for (uint32_t i : listed(h_ov.data(), nt))                    // slices with an overfull bucket, or beyond one workgroup (the row-sweep form cuts those into pieces)
+            if (fused ? h_valid[i] > 1 : (h_slice[i] > 1 && h_slice[i] <= PBA_IX_LDS_SORT_CAP)) {
+                rc = sort_partition_global(ctx, d_cand.as<uint64_t>() + h_off[i], fused ? h_valid[i] : h_slice[i]);
                 if (rc != PBA_OK) return rc;
             }
         for (uint32_t i : listed(h_ov.data() + 1 + ov_cap, h_pieces.size()))   // pieces beyond one sort, or with an overfull bucket
@@ -434,24 +399,23 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     HIPCHK(hipGetLastError());
     uint64_t n_valid = 0;
     for (uint32_t i = 0; i < nt; ++i) n_valid += h_valid[i];
-    st.n_candidates = n_valid;
+    st.n_candidates = fused ? n_cand : n_valid;
+    st.n_listed = n_valid;
 
     // 4. walk: persistent wavefronts, one target at a time, narrow window; then the parked (target, query) runs
     //    at the reference band
-    POOL(POOL_OVL_OUT, sizeof(pba_overlap) * (cap + 1), d_out.p);
+    // (the device list holds every success -- there are no more of them than listed candidates -- whatever the caller's cap:
+    // k_ovl_after goes through all of them)
+    const uint64_t dev_cap = fused ? std::max<uint64_t>(cap, n_valid) : cap;
+    POOL(POOL_OVL_OUT, sizeof(pba_overlap) * (dev_cap + 1), d_out.p);
     HIPCHK(hipMemsetAsync(d_cnt64.p, 0, 32, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
     const size_t lds = pl.lds;
     BufRef d_redo;
-    const std::vector<uint32_t> &h_wcnt = prekeep ? h_kept : h_valid;      // what the walk sees of every target
-    // (the walk takes a count per target: with the packed list, target t's is the distance to the next offset)
-    BufRef d_kcnt;
-    if (prekeep) {
-        d_kcnt.p = d_small.as<uint32_t>() + 2 * ((size_t)nt + 1);            // d_valid's place: its host copy is what is used from here on
-        HIPCHK(hipMemcpyAsync(d_kcnt.p, h_kept.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, ctx->stream));
-    }
-    const uint32_t *const d_wcnt = prekeep ? d_kcnt.as<uint32_t>() : d_valid.as<uint32_t>();
-    const uint32_t *const d_woff = prekeep ? d_koff : d_off.as<uint32_t>();
+    const std::vector<uint32_t> &h_wcnt = h_valid;               // what the walk sees of every target
+    const uint32_t *const d_wcnt = d_valid.as<uint32_t>();
+    const uint32_t *const d_woff = d_off.as<uint32_t>();
+    BufRef d_items;
     uint64_t n_walk = 0;
     for (uint32_t i = 0; i < nt; ++i) n_walk += h_wcnt[i];
     // every (target, query) run can park at most once per stage, and there are no more runs than candidates
@@ -547,11 +511,22 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         if (rc != PBA_OK) return rc;
     }
     st.n_redo = parked_total;
-    (void)hipEventRecord(ctx->ev[5], ctx->stream);
     HIPCHK(hipGetLastError());
     unsigned long long h_cnt2[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(h_cnt2, d_cnt64.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    // 5. pairs.  Row-sweep form: the walk counted what it tried.  Fused form: the scan counted every candidate past the gate
+    //    as a pair; what lies behind the first success of a run was never tried (overlap.h: k_ovl_after)
+    unsigned long long h_after = 0;
+    if (fused && h_cnt2[0]) {
+        const uint32_t n_ov = (uint32_t)std::min<uint64_t>(h_cnt2[0], dev_cap);
+        hipLaunchKernelGGL(k_ovl_after, dim3((n_ov + 3) / 4), dim3(PBA_WAVE * 4), 0, ctx->stream, reads->dev(), d_out.as<pba_overlap>(), n_ov,
+                           T.mask, t2, overlap_min, d_cnt64.as<unsigned long long>() + 6);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&h_after, d_cnt64.as<unsigned long long>() + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipEventRecord(ctx->ev[5], ctx->stream);
     const uint64_t got = std::min<uint64_t>(h_cnt2[0], cap);
     if (got) HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_overlap) * got, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -560,7 +535,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     });
     *n_out = h_cnt2[0];
     st.n_overlaps = h_cnt2[0];
-    st.n_pairs = h_cnt2[1] + n_dropped;
+    st.n_pairs = fused ? n_ok - h_after : h_cnt2[1];
     (void)hipEventElapsedTime(&st.scan_ms, ctx->ev[2], ctx->ev[3]);
     (void)hipEventElapsedTime(&st.sort_ms, ctx->ev[3], ctx->ev[4]);
     (void)hipEventElapsedTime(&st.walk_ms, ctx->ev[4], ctx->ev[5]);

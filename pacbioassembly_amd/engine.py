@@ -425,7 +425,7 @@ def _overlap_all_sharded(self, reads, mask, R, max_trial=32, overlap_min=64, tar
         if total is None:
             total = dict(st)
         else:
-            for k in ("n_candidates", "n_pairs", "n_overlaps", "n_redo", "scan_ms", "sort_ms", "walk_ms", "n_big_targets", "n_prefiltered", "cap_fill", "cap_overflow"):
+            for k in ("n_candidates", "n_pairs", "n_overlaps", "n_redo", "scan_ms", "sort_ms", "walk_ms", "n_big_targets", "n_prefiltered", "cap_fill", "cap_overflow", "n_listed"):
                 total[k] += st[k]
             total["wide_first"] = max(total["wide_first"], st["wide_first"])
     if own:

@@ -633,17 +633,18 @@ def test_locate_ecoli_scale_genome_vs_oracle(ctx, oracle):
     assert wst["n_located"] > 250 and wst["n_pairs"] > wst["n_located"]
 
 
-@pytest.fixture(params=["sorted_whole", "prefiltered_before_the_sort", "scan_emits_cooperatively"])
+@pytest.fixture(params=["census_then_exact_slices", "equal_room", "equal_room_overflows"])
 def prekeep(request, monkeypatch):
-    """The all-vs-all tests run twice: as small calls run by default (every candidate is sorted and walked), and with the stage
-    big calls get (>= 2^29 candidates) forced on -- the first prefilter stage before the sort, runs without a survivor
-    counted and dropped (overlap.h: k_ovl_pre / k_ovl_keep) -- and a third time with the fill pass emitting cooperatively, the form
-    it takes when runs are long.  Same overlaps, same pair counts, all against the oracle."""
-    if request.param == "prefiltered_before_the_sort":
-        monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
-    if request.param == "scan_emits_cooperatively":               # the fill pass's form for millions of reads (runs of >= 6 probes), forced
-        monkeypatch.setenv("PBA_OVL_COOP_AVG", "0")
-    return request.param == "prefiltered_before_the_sort"
+    """The all-vs-all tests run three times, once per way the scan of the bit-vector kernels (overlap.h: k_ovl_scan -- the first
+    32 rows of every candidate run where it is found, only survivors are written) sizes the survivors' slices: a census
+    launch and exact slices (what the first range of a table gets), equal room for every target (what later ranges get from
+    the census of an earlier one; forced here), and equal room that some target outgrows, so that the range is scanned
+    again with exact slices.  Same overlaps, same pair counts, all against the oracle."""
+    if request.param == "equal_room":
+        monkeypatch.setenv("PBA_OVL_ROOM", "16384")
+    if request.param == "equal_room_overflows":
+        monkeypatch.setenv("PBA_OVL_ROOM", "4")
+    return request.param
 
 
 # ----------------------------------------------------------------------------- all-vs-all overlap
@@ -674,7 +675,8 @@ def test_overlap_all_vs_oracle_composition(ctx, oracle, kernel, prekeep):
     got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=kernel)
     assert [tuple(int(x) for x in r) for r in got] == want
     assert st["n_overlaps"] == len(want) and st["n_pairs"] == pairs and st["n_candidates"] >= st["n_pairs"]
-    assert (st["n_prefiltered"] > 0) == (prekeep and kernel != PBA_KERNEL_ROWSWEEP)
+    assert (st["n_prefiltered"] > 0) == (kernel != PBA_KERNEL_ROWSWEEP)       # failed their first 32 rows in the scan: counted, never written
+    assert kernel == PBA_KERNEL_ROWSWEEP or st["cap_overflow"] == (prekeep == "equal_room_overflows")
     # target shards (what ranks of a multi-GPU run do) concatenate to the same answer
     parts = [ctx.overlap_all(S, mask, 0.30, 32, 64, t_lo=a, t_hi=b, kernel=kernel)[0] for a, b in ((0, 20), (20, 21), (21, 64))]
     assert [tuple(int(x) for x in r) for p in parts for r in p] == want
@@ -822,7 +824,9 @@ def test_overlap_many_target_ranges_and_the_limits_of_a_call(ctx, oracle, monkey
         lo, hi = np.searchsorted(many["target"], [t, t + 1])
         assert [tuple(int(x) for x in r) for r in many[lo:hi]] == exp and len(exp) >= 1, t
     # a call that would hold more candidates than its offsets can address refuses; ranges below the limit go through
-    monkeypatch.setenv("PBA_OVL_MAX_CANDIDATES", str(st1["n_candidates"] // 10))
+    # (what is held are the LISTED candidates: the survivors of the scan's 32 rows -- a tenth of the candidates of these short reads)
+    assert 0 < st1["n_listed"] < st1["n_candidates"] // 5 and st1["n_listed"] + st1["n_prefiltered"] >= st1["n_pairs"]
+    monkeypatch.setenv("PBA_OVL_MAX_CANDIDATES", str(st1["n_listed"] // 10))
     with pytest.raises(PbaError) as e:
         ctx.overlap_all(S, mask, 0.30, 32, 64, cap=16)
     assert e.value.status == -4                                      # PBA_E_TOOLONG
@@ -1367,11 +1371,11 @@ def test_locate_random_configs_vs_oracle():
 
 
 def test_overlap_later_ranges_of_a_table_skip_the_count_pass(ctx, monkeypatch):
-    """Capacity mode: after one counted range of >= 1 024 targets the next ranges against the same probe table get equal room
-    per target (1.25 x the largest slice seen) instead of a count pass, and go through the pre-sort stage; a slice that
-    outgrows its room sends the range through the counted way again.  2 600 short reads in ranges of 1 300 targets: same rows
-    and counts as the row-sweep kernel in one call -- with the room as sized, with room for half the largest slice (every
-    later range overflows and is redone), and with the mode switched off."""
+    """After the census of one range of >= 1 024 targets the next ranges against the same probe table get equal room per target
+    (1.25 x the largest need seen) instead of a census launch; a target that outgrows its room sends the range through the
+    scan again with exact slices.  2 600 short reads in ranges of 1 300 targets: same rows and counts as the row-sweep kernel
+    in one call -- with the room as sized, with room for half the largest need (every later range overflows and is redone),
+    and with the mode switched off."""
     g = eng.synth_genome(401, 260000)
     n, rl = 2600, 1500
     reads, offs, _ = eng.synth_reads(402, g, n, rl, 0.02, 0.02, 0.02)
@@ -1379,18 +1383,11 @@ def test_overlap_later_ranges_of_a_table_skip_the_count_pass(ctx, monkeypatch):
     mask = eng.mask_from_pattern(MASK_PAT)
     want, wst = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_ROWSWEEP)
     assert len(want) > 10000
-    monkeypatch.setenv("PBA_OVL_PREKEEP_MIN", "0")
-    # ... and all of it a second time with the fill pass emitting cooperatively (the form runs of >= 6 probes get: millions of
-    # reads), which is how production sizes run capacity mode: its clipping at the slice's room and its count of what a target
-    # needed are live in the overflow-and-redo case
-    for coop in (None, "0"):
-        if coop is not None:
-            monkeypatch.setenv("PBA_OVL_COOP_AVG", coop)
-        for pct, n_cap, n_over in (("125", 1, 0), ("50", 1, 1), ("0", 0, 0)):
-            monkeypatch.setenv("PBA_OVL_CAPFILL_PCT", pct)
-            got, st = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=1300, kernel=PBA_KERNEL_BITVEC)
-            assert (got == want).all() and st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"], (coop, pct)
-            assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (coop, pct, st)
+    for pct, n_cap, n_over in (("125", 1, 0), ("50", 1, 1), ("0", 0, 0)):
+        monkeypatch.setenv("PBA_OVL_CAPFILL_PCT", pct)
+        got, st = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=1300, kernel=PBA_KERNEL_BITVEC)
+        assert (got == want).all() and st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"], pct
+        assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (pct, st)
 
 
 def test_overlap_random_read_sets_bitvec_forms_vs_rowsweep():

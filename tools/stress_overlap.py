@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Differential stress of the all-vs-all path: the bit-vector walk with everything round 2 put around it (pre-sort prefilter
-stage forced on and off, early give-up of narrow passes, parked runs through the rings) against the row-sweep kernel,
+"""Differential stress of the all-vs-all path: the bit-vector form (first 32 rows in the scan, survivors only in memory --
+with census + exact slices and with equal room that overflows --, early give-up of narrow passes, parked runs through the
+rings, pairs = candidates - what lies behind a success) against the row-sweep kernel,
 which has no windows, no prefilter and no certificates -- same overlaps row by row, same pair counts.  Random read sets:
 lengths from below the 500-base cut to 16 kb, per-read error from 1 % to 17 %, indel-heavy and substitution-heavy mixes,
 coverage 4x-30x.  Prints one line per round; exits 1 on the first disagreement."""
@@ -37,16 +38,16 @@ for rnd in range(a.rounds):
     mask = eng.mask_from_pattern(masks[rnd % len(masks)])
     R = float(rng.choice([0.15, 0.25, 0.30, 0.35]))
     trials = int(rng.choice([8, 32]))
-    os.environ.pop("PBA_OVL_PREKEEP_MIN", None)
+    os.environ.pop("PBA_OVL_ROOM", None)
     want, wst = ctx.overlap_all(S, mask, R, trials, 64, kernel=PBA_KERNEL_ROWSWEEP)
     line = f"round {rnd}: {n} reads x {rl} @ {e:.2f} ({mix[0]:.3f}/{mix[1]:.3f}/{mix[2]:.3f}) cov {cov:.0f} R {R} trials {trials}: " \
            f"{len(want)} overlaps, {wst['n_pairs']} pairs, {wst['n_candidates']} candidates"
-    for mode in ("0", "1000000000000"):
-        os.environ["PBA_OVL_PREKEEP_MIN"] = mode
+    for mode in ("0", "8"):                                        # census + exact slices; equal room that overflows and is redone
+        os.environ["PBA_OVL_ROOM"] = mode
         got, st = ctx.overlap_all(S, mask, R, trials, 64, kernel=PBA_KERNEL_BITVEC)
         ok = (got.size == want.size and (got == want).all() and st["n_pairs"] == wst["n_pairs"]
               and st["n_candidates"] == wst["n_candidates"])
-        line += f" | prekeep {'on' if mode == '0' else 'off'}: {'same' if ok else 'DIFFERENT'} (redo {st['n_redo']}, prefiltered {st['n_prefiltered']})"
+        line += f" | room {mode}: {'same' if ok else 'DIFFERENT'} (redo {st['n_redo']}, prefiltered {st['n_prefiltered']}, overflow {st['cap_overflow']})"
         bad += not ok
     print(line, flush=True)
     S.close()
