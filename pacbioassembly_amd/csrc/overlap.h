@@ -159,8 +159,8 @@ k_pt_ctx(ProbeTab T, SeqSetDev Rd, uint32_t n_entries) {
 #define PBA_OVL_PPT 16                                         // positions per thread and step
 #define PBA_OVL_WAVES 4                                        // wavefronts per workgroup
 #ifndef PBA_OVL_HALF
-#define PBA_OVL_HALF 16                                        // positions per thread whose runs are compacted together
-#endif
+#define PBA_OVL_HALF 8                                         // positions per thread whose runs are compacted together (tuning hook; the scan
+#endif                                                         // of 400 k reads: 16 -> 347 ms, 8 -> 296 ms, 4 -> 300 ms: LDS per workgroup, so occupancy)
 #define PBA_OVL_RUNS (PBA_WAVE * PBA_OVL_HALF)                 // runs a wavefront can meet in one round
 
 struct TargetWalk {          // visiting order of ref_seq::get_seedmap as a function of the position
@@ -348,14 +348,21 @@ static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
 k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *surv_off, uint64_t *surv, uint32_t slice_cap,
            uint32_t *needed, OvlCfg cfg, PreThresholds pre_t, unsigned long long *totals) {
     PBA_OVL_RUN_LISTS(HASHED);
+    __shared__ uint32_t r_mark[PBA_OVL_WAVES][2];
     __shared__ uint32_t cursor, s_cand, s_ok;
+    extern __shared__ __align__(16) uint32_t s_planes[];           // the target's bit planes: pairs 0 .. len / 32 + 1 (the host sizes it)
     const uint32_t tl = blockIdx.x, t = t_lo + tl;
     const int lane = threadIdx.x & (PBA_WAVE - 1), w = threadIdx.x / PBA_WAVE;
     if (threadIdx.x == 0) { cursor = 0; s_cand = 0; s_ok = 0; }
-    __syncthreads();
     const int len = (int)Rd.len[t];
     const uint8_t *seq = Rd.packed + Rd.off[t];
-    const PackedFetch tf = fetch_of(Rd, t, 0, 1);
+    {   // every candidate's rows come from here: 16 bytes at a random place of the target per candidate
+        const uint32_t *gp = Rd.plane + 2 * Rd.poff[t];
+        const int nw = 2 * (len / 32 + 2);
+        for (int k = (int)threadIdx.x; k < nw; k += PBA_WAVE * PBA_OVL_WAVES) s_planes[k] = gp[k];
+    }
+    __syncthreads();
+    const PackedFetch tf{seq, 0, 1, s_planes};
     const TargetWalk tw(len);
     const HeadTail ht(len);
     uint64_t *out = surv_off ? surv + surv_off[tl] : nullptr;
@@ -369,16 +376,42 @@ k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
 #pragma unroll
         for (int h0 = 0; h0 < PBA_OVL_PPT; h0 += PBA_OVL_HALF) {
             PBA_OVL_COMPACT();
+            // 64 consecutive slots of the concatenated runs per iteration.  Which run a slot belongs to: `ra` is the run of
+            // slot0 (wave-uniform, carried along); lane l looks at the start of run ra + 1 + l -- at most 64 runs can begin in 64
+            // slots -- and marks it in a 64-bit mask in LDS; a lane's run is ra + the marks at or below its slot.  (A binary
+            // search per lane over the prefix sums cost ten dependent LDS round trips per iteration.)
+            // The records of the NEXT 64 slots are requested before this iteration's 32 rows are swept.
+            uint32_t ra = 0;
+            auto locate = [&](uint32_t slot0, uint32_t &run, uint32_t &ra_next) {
+                const uint32_t nxt = ra + 1u + (uint32_t)lane;
+                const uint32_t d = (nxt <= R ? r_rel[w][nxt] : 0xFFFFFFFFu) - slot0;      // >= 1: run ra holds slot0
+                if (lane == 0) { r_mark[w][0] = 0u; r_mark[w][1] = 0u; }
+                __builtin_amdgcn_wave_barrier();
+                if (d < PBA_WAVE) atomicOr(&r_mark[w][d >> 5], 1u << (d & 31u));
+                __builtin_amdgcn_wave_barrier();
+                const uint64_t M = (uint64_t)r_mark[w][1] << 32 | r_mark[w][0];
+                run = ra + (uint32_t)__builtin_popcountll(M & ((2ull << lane) - 1ull));
+                ra_next = ra + (uint32_t)__builtin_popcountll(M) + (__builtin_amdgcn_ballot_w64(d == PBA_WAVE) ? 1u : 0u);
+                __builtin_amdgcn_wave_barrier();
+            };
+            uint32_t run_n, ra_n;
+            locate(0u, run_n, ra_n);
+            uint32_t e_n = r_s0[w][min(run_n, R - 1)] + ((uint32_t)lane < Tot ? (uint32_t)lane - r_rel[w][min(run_n, R - 1)] : 0u);
+            if ((uint32_t)lane >= Tot) { run_n = R - 1; e_n = r_s0[w][R - 1]; }           // (a lane without a slot reads its wavefront's last run's first record)
+            uint4 rec_n = T.prec[e_n];
             for (uint32_t slot0 = 0; slot0 < Tot; slot0 += PBA_WAVE) {
                 const uint32_t slot = slot0 + (uint32_t)lane;
                 const bool have = slot < Tot;
-                uint32_t lo_r = 0, hi_r = R;                             // last run with r_rel <= slot
-                while (hi_r - lo_r > 1) {
-                    const uint32_t mid = (lo_r + hi_r) >> 1;
-                    if (r_rel[w][mid] <= slot) lo_r = mid; else hi_r = mid;
+                const uint32_t lo_r = run_n, e = e_n;
+                const uint4 rec = rec_n;
+                ra = ra_n;
+                if (slot0 + PBA_WAVE < Tot) {                            // the next iteration's records, in flight under this one's arithmetic
+                    locate(slot0 + PBA_WAVE, run_n, ra_n);
+                    const uint32_t s2 = slot + PBA_WAVE;
+                    if (s2 < Tot) e_n = r_s0[w][run_n] + (s2 - r_rel[w][run_n]);
+                    else { run_n = R - 1; e_n = r_s0[w][R - 1]; }
+                    rec_n = T.prec[e_n];
                 }
-                const uint32_t e = r_s0[w][lo_r] + (have ? slot - r_rel[w][lo_r] : 0u);
-                const uint4 rec = T.prec[e];                             // (a lane without a slot reads its run's first record)
                 const uint32_t q = rec.x >> PBA_OVL_JD_BITS, jd = rec.x & ((1u << PBA_OVL_JD_BITS) - 1);
                 bool valid = have && q != t;
                 if (HASHED) valid = valid && T.pkey[e] == r_key[w][lo_r];
@@ -394,7 +427,7 @@ k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
                 int fr = 0;
                 if (prefilter32_applies(ok, r_len, s_len, cfg.R, 0, 0, po)) {
                     uint32_t alo, ahi;
-                    load_planes32(tf.at(r_off, fwd ? 1 : -1), 0, alo, ahi);          // rows: the target from its hit
+                    load_planes32(tf.at(r_off, fwd ? 1 : -1), 0, alo, ahi);          // rows: the target from its hit (its planes are in LDS)
                     fr = prefilter32_planes(alo, ahi, rec.z, rec.w, pre_t);          // columns: the probe's record
                 }
                 const bool survivor = ok && fr == 0;

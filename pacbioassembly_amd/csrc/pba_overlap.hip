@@ -243,11 +243,12 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         if (room == 0)
             if (const char *e = getenv("PBA_OVL_ROOM")) room = (uint32_t)std::max(0, atoi(e));   // test hook: equal room (and its overflow path) in a table's first range
         const PreThresholds pre_t = PreThresholds::on_host(R);
+        const size_t plane_lds = sizeof(uint32_t) * 2 * ((size_t)reads->max_len / 32 + 2);     // the target's bit planes (k_ovl_scan)
         auto scan = [&](bool write, uint32_t cap_slots) -> int {
             HIPCHK(hipMemsetAsync(d_cnt64.as<unsigned long long>() + 4, 0, 16, ctx->stream));
             const uint32_t *so = write ? d_off.as<uint32_t>() : nullptr;
-            if (tab->hashed) hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
-            else hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), 0, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
+            if (tab->hashed) hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), plane_lds, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
+            else hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), plane_lds, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
