@@ -75,6 +75,8 @@ def parse():
                     help="locate mode: seconds after which the extra all-vs-all leg is given up and the headline line printed without it")
     ap.add_argument("--timeout", type=int, default=3000,
                     help="--mode overlap: seconds after which a rank that has not finished gives up with exit code 4")
+    ap.add_argument("--overlap-check", type=int, default=3,
+                    help="all-vs-all: targets of rank 0's shard re-done by the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--coverage", type=float, default=20.0, help="all-vs-all: genome = reads x read_len / coverage")
     ap.add_argument("--overlap-trials", type=int, default=32)
     ap.add_argument("--targets-per-call", type=int, default=40_000)
@@ -220,6 +222,8 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
     assert S.count == n
     cap = ((n + world - 1) // world) * 2 * trials + 64     # probe slots of the largest shard
 
+    last = {}
+
     def step(t_hi=None):
         t_a = time.perf_counter()
         mine = torch.empty(cap, dtype=torch.int64, device="cuda")
@@ -237,6 +241,7 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
         table.close()
         st["exchange_s"] = t_x
         st["step_s"] = time.perf_counter() - t_a
+        last["ov"] = ov
         return st
 
     def fence():
@@ -269,6 +274,11 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
         counts = [int(x) for x in agg.tolist()]
     else:
         allt = np.array([mine_t])
+    # ---- outside the timed region: the oracle on sampled targets of this rank's shard, every read of the set a query --
+    # capacity-sized slices, the scan's 32 rows, the cascade of windows and k_ovl_after are all live at this size
+    spot = None
+    if rank == 0 and a.overlap_check > 0:
+        spot = oracle_spot_check(ctx, S, last["ov"], r_lo, r_hi, n, rl, mask, a.R, trials, a.overlap_check, nthreads)
     S.close()
     if rank != 0:
         return None
@@ -283,6 +293,7 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
         "seconds_per_step": round(elapsed / steps, 4), "pairs_per_step": counts[0], "overlaps_per_step": counts[1],
         "candidates_per_step": counts[2], "pairs_per_s": round(counts[0] * steps / elapsed, 1),
         "overlaps_per_s": round(counts[1] * steps / elapsed, 1),
+        "oracle_sample_identical": None if spot is None else spot["identical"], "oracle_sample": spot,
         "exchange_s": round(float(allt[:, 1].max()), 4), "read_gather_s": round(float(allt[:, 8].max()), 3),
         "per_rank": {"scan_s": [round(float(x), 4) for x in allt[:, 2]], "sort_s": [round(float(x), 4) for x in allt[:, 3]],
                      "walk_s": [round(float(x), 4) for x in allt[:, 4]], "table_s": [round(float(x), 4) for x in allt[:, 5]],
@@ -292,6 +303,45 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
                           "frac": round(scan_bytes / world / scan_s / HBM_PEAK, 5) if scan_s > 0 else None,
                           "note": "per GPU: 0.25 B per visited position + 8 B per candidate written, over the slowest rank's scan time"},
     }
+
+
+def oracle_spot_check(ctx, S, ov, t_lo, t_hi, n, rl, mask, R, trials, k, nthreads):
+    """The CPU oracle's locked round (orc_spaced_round: spaced_seed.cpp:420-437 with the intended seed_at) with target t as the
+    reference and EVERY read of the set as a query, for k targets spread over [t_lo, t_hi): its successful rows must be the rows
+    the GPU reported for t.  The read file of the oracle is put together from the packed reads on the device (uniform read
+    length: [u32 length][packed bases] records, dna_seq.h:113-127)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oraclelib import Oracle
+    t0 = time.perf_counter()
+    nb = S.packed_bytes
+    buf = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
+    offs = S.export(buf.data_ptr(), nb)
+    host = buf.cpu().numpy()
+    del buf
+    pk = (rl + 3) // 4
+    stride = int(offs[1] - offs[0]) if n > 1 else pk
+    assert (S.lengths() == rl).all() and stride >= pk and int(offs[0]) == 0
+    rec = np.empty((n, 4 + pk), np.uint8)
+    rec[:, :4] = np.frombuffer(np.uint32(rl).tobytes(), np.uint8)
+    rec[:, 4:] = host[: n * stride].reshape(n, stride)[:, :pk]
+    file = rec.tobytes()
+    del rec, host
+    rec_offs = np.arange(n, dtype=np.uint64) * np.uint64(4 + pk)
+    orc = Oracle()
+    picks = sorted({t_lo + (i * (t_hi - t_lo - 1)) // max(k - 1, 1) for i in range(k)})
+    same, rows_checked = True, 0
+    for t in picks:
+        rows = orc.spaced_round(S.get_text(t), mask, R, file, rec_offs, trials, 64, buggy=False, nthreads=nthreads)
+        exp = [(t, int(q), int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]), int(rows["matlen_a"][q]),
+                int(rows["matlen_b"][q])) for q in np.nonzero(rows["found"])[0] if q != t]
+        lo, hi = np.searchsorted(ov["target"], [t, t + 1])
+        got = [tuple(int(x) for x in r) for r in ov[lo:hi]]
+        same = same and got == exp
+        rows_checked += len(exp)
+    return {"identical": bool(same), "targets": picks, "overlap_rows": rows_checked, "queries_per_target": n - 1,
+            "seconds": round(time.perf_counter() - t0, 1), "cores": nthreads}
 
 
 def guarded_overlap(a, ctx, rank, world, nthreads, headline):

@@ -335,7 +335,7 @@ struct OvlCfg {
 // and dropped at that row: it is COUNTED and never exists in memory.  A survivor (1.4 % at R = 0.30, plus every true
 // overlap) is written to the target's slice.  What the reference would not have aligned at all -- candidates of a (target,
 // query) run behind that run's first success -- is taken off the count afterwards, per success (k_ovl_after).
-//   surv_off == nullptr: nothing is written (the first range of a table: how much room a target needs)
+//   surv_off == nullptr: nothing is written (the first range of a table: how much room a target needs, from a sample of its targets)
 //   slice_cap          : slots a target may write (equal room from an earlier range's census, or its exact need)
 //   needed[tl]         : survivors the target produced, written or not (> slice_cap: the host runs the range again, exact)
 //   totals[0] += seed matches (entries of other reads under the same key), totals[1] += candidates past the OVERLAP_MIN
@@ -345,13 +345,13 @@ struct OvlCfg {
 // + sort 2.57 s of a 5.4 s run; each false candidate now costs its share of one coalesced record line and ~9 instructions.
 template <bool HASHED>
 static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
-k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const uint32_t *surv_off, uint64_t *surv, uint32_t slice_cap,
+k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t t_stride, const uint32_t *surv_off, uint64_t *surv, uint32_t slice_cap,
            uint32_t *needed, OvlCfg cfg, PreThresholds pre_t, unsigned long long *totals) {
     PBA_OVL_RUN_LISTS(HASHED);
     __shared__ uint32_t r_mark[PBA_OVL_WAVES][2];
     __shared__ uint32_t cursor, s_cand, s_ok;
     extern __shared__ __align__(16) uint32_t s_planes[];           // the target's bit planes: pairs 0 .. len / 32 + 1 (the host sizes it)
-    const uint32_t tl = blockIdx.x, t = t_lo + tl;
+    const uint32_t tl = blockIdx.x * t_stride, t = t_lo + tl;      // (t_stride > 1: a census over every t_stride-th target, needed[] by workgroup)
     const int lane = threadIdx.x & (PBA_WAVE - 1), w = threadIdx.x / PBA_WAVE;
     if (threadIdx.x == 0) { cursor = 0; s_cand = 0; s_ok = 0; }
     const int len = (int)Rd.len[t];
@@ -450,7 +450,7 @@ k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t n_targets, const ui
     if (lane == 0) { atomicAdd(&s_cand, ncand); atomicAdd(&s_ok, nok); }
     __syncthreads();
     if (threadIdx.x == 0) {
-        needed[tl] = cursor;
+        needed[blockIdx.x] = cursor;
         atomicAdd(&totals[0], (unsigned long long)s_cand);
         atomicAdd(&totals[1], (unsigned long long)s_ok);
     }

@@ -234,31 +234,42 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         //    slices; later ranges give every target the same room -- 1.25 x the largest need seen, + 64 -- and fall back to
         //    exact slices (needed[] of the clipped run) when a target outgrows it.
         uint32_t room = 0;
+        int pct = 125;
+        if (const char *e = getenv("PBA_OVL_CAPFILL_PCT")) pct = atoi(e);         // test hook: 0 = never equal room (a full census per range), small = overflow and fall back
         if (tab->slice_max > 0) {
-            int pct = 125;
-            if (const char *e = getenv("PBA_OVL_CAPFILL_PCT")) pct = atoi(e);     // test hook: 0 = never, small = overflow and fall back
             const uint64_t c = (uint64_t)tab->slice_max * (uint64_t)std::max(0, pct) / 100 + 64;
             if (pct > 0 && c * nt < max_cand) room = (uint32_t)c;
         }
-        if (room == 0)
-            if (const char *e = getenv("PBA_OVL_ROOM")) room = (uint32_t)std::max(0, atoi(e));   // test hook: equal room (and its overflow path) in a table's first range
+        if (const char *e = getenv("PBA_OVL_ROOM"))              // test hook: this much room for every target of every range (and so the overflow path at will)
+            if (atoi(e) > 0) room = (uint32_t)atoi(e);
         const PreThresholds pre_t = PreThresholds::on_host(R);
         const size_t plane_lds = sizeof(uint32_t) * 2 * ((size_t)reads->max_len / 32 + 2);     // the target's bit planes (k_ovl_scan)
-        auto scan = [&](bool write, uint32_t cap_slots) -> int {
+        auto scan = [&](bool write, uint32_t cap_slots, uint32_t grid, uint32_t stride) -> int {
             HIPCHK(hipMemsetAsync(d_cnt64.as<unsigned long long>() + 4, 0, 16, ctx->stream));
             const uint32_t *so = write ? d_off.as<uint32_t>() : nullptr;
-            if (tab->hashed) hipLaunchKernelGGL(k_ovl_scan<true>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), plane_lds, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
-            else hipLaunchKernelGGL(k_ovl_scan<false>, dim3(nt), dim3(PBA_WAVE * PBA_OVL_WAVES), plane_lds, ctx->stream, T, reads->dev(), t_lo, nt, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
+            if (tab->hashed) hipLaunchKernelGGL(k_ovl_scan<true>, dim3(grid), dim3(PBA_WAVE * PBA_OVL_WAVES), plane_lds, ctx->stream, T, reads->dev(), t_lo, stride, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
+            else hipLaunchKernelGGL(k_ovl_scan<false>, dim3(grid), dim3(PBA_WAVE * PBA_OVL_WAVES), plane_lds, ctx->stream, T, reads->dev(), t_lo, stride, so, d_cand.as<uint64_t>(), cap_slots, d_slice.as<uint32_t>(), ocfg, pre_t, d_cnt64.as<unsigned long long>() + 4);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(h_slice.data(), d_slice.p, sizeof(uint32_t) * grid, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             return PBA_OK;
         };
         bool have_exact = false;
         if (room == 0) {
-            rc = scan(false, 0);                                 // census
+            // census: all targets of a small range, every k-th of a big one (a sixteenth of the work; what it misses the
+            // overflow path catches)
+            uint32_t n_s = pct > 0 ? std::min<uint32_t>(nt, std::max<uint32_t>(64u, nt / 16u)) : nt;
+            const uint32_t stride = nt / n_s;
+            if (stride == 1) n_s = nt;                           // (no sample worth the name: every target)
+            rc = scan(false, 0, n_s, stride);
             if (rc != PBA_OK) return rc;
-            have_exact = true;
+            if (stride == 1) have_exact = true;
+            else {
+                uint32_t mx = 0;
+                for (uint32_t i = 0; i < n_s; ++i) mx = std::max(mx, h_slice[i]);
+                room = mx + mx / 2 + 64;
+                if ((uint64_t)room * nt >= max_cand) { rc = scan(false, 0, nt, 1); if (rc != PBA_OK) return rc; have_exact = true; }   // (too much room to hand out blindly)
+            }
         }
         for (int attempt = 0; attempt < 2; ++attempt) {
             uint64_t extent = 0;
@@ -276,12 +287,17 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
             h_off[nt] = (uint32_t)extent;
             HIPCHK(hipMemcpyAsync(d_off.p, h_off.data(), sizeof(uint32_t) * (nt + 1), hipMemcpyHostToDevice, ctx->stream));
             POOL(POOL_OVL_CAND, sizeof(uint64_t) * (extent + 1), d_cand.p);
-            rc = scan(true, have_exact ? 0xFFFFFFFFu : room);
+            rc = scan(true, have_exact ? 0xFFFFFFFFu : room, nt, 1);
             if (rc != PBA_OK) return rc;
             if (have_exact) break;
             bool over = false;
-            for (uint32_t i = 0; i < nt; ++i) over = over || h_slice[i] > room;
-            if (!over) { st.cap_fill = 1; break; }
+            uint32_t mx = 0;
+            for (uint32_t i = 0; i < nt; ++i) { over = over || h_slice[i] > room; mx = std::max(mx, h_slice[i]); }
+            if (!over) {
+                st.cap_fill = 1;
+                if (nt >= 1024 || tab->slice_max == 0) tab->slice_max = std::max(mx, 1u);     // what a later range goes by
+                break;
+            }
             st.cap_overflow = 1;                                 // a target outgrew its room: once more, with what each one needed
             have_exact = true;
         }

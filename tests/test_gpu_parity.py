@@ -1390,6 +1390,38 @@ def test_overlap_later_ranges_of_a_table_skip_the_count_pass(ctx, monkeypatch):
         assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (pct, st)
 
 
+def test_overlap_15kb_reads_sampled_targets_vs_oracle(ctx, oracle, monkeypatch):
+    """BASELINE configs[3]'s read shape at a size the oracle can spot-check: 2 400 x 15 kb reads @15 % at 20 x coverage through
+    ONE probe table in three target ranges -- sampled census, equal-room slices from the second range on, the scan's 32 rows,
+    the sampled narrow / wide decision, parked runs through the rings, pairs = candidates - what lies behind a success -- and
+    the oracle's locked round (every read a query) on five targets spread over the ranges: same rows.  The whole set again
+    with room that overflows (every range scanned twice): same rows, same counts."""
+    n, rl = 2400, 15000
+    g = eng.synth_genome(77, n * rl // 20)
+    reads, offs, _ = eng.synth_reads(78, g, n, rl, nthreads=16)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    S = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    monkeypatch.setenv("PBA_OVL_SAMPLE_MIN", "64")                  # the sampled window decision at this size
+    got, st = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=800, cap_per_target=400)
+    assert st["n_overlaps"] == len(got) > 8000 and st["n_prefiltered"] > 5 * st["n_listed"] and st["cap_fill"] >= 2
+    texts = lambda i: reads[int(offs[i]):int(offs[i + 1])].tobytes()
+    file = b"".join(eng.text2bin(texts(i)) for i in range(n))
+    rec_offs = (np.arange(n, dtype=np.uint64) * np.uint64(4 + (rl + 3) // 4))
+    pairs = 0
+    for t in (0, 799, 800, 1733, n - 1):
+        rows = oracle.spaced_round(texts(t), mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=16)
+        exp = [(t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]), int(rows["matlen_a"][q]),
+                int(rows["matlen_b"][q])) for q in np.nonzero(rows["found"])[0] if q != t]
+        lo, hi = np.searchsorted(got["target"], [t, t + 1])
+        assert [tuple(int(x) for x in r) for r in got[lo:hi]] == exp and len(exp) >= 1, t
+        # ... and the pairs of that target alone, through a one-target call
+        one, st1 = ctx.overlap_all(S, mask, 0.30, 32, 64, t_lo=t, t_hi=t + 1)
+        assert st1["n_pairs"] == int(rows["n_pairs"].sum()) - int(rows["n_pairs"][t]), t
+    monkeypatch.setenv("PBA_OVL_ROOM", "12")                        # every range overflows and is scanned again with exact slices
+    again, st2 = ctx.overlap_all_sharded(S, mask, 0.30, 32, 64, targets_per_call=800, cap_per_target=400)
+    assert (again == got).all() and st2["n_pairs"] == st["n_pairs"] and st2["n_candidates"] == st["n_candidates"] and st2["cap_overflow"] >= 2
+
+
 def test_overlap_random_read_sets_bitvec_forms_vs_rowsweep():
     """tools/stress_overlap.py: all-vs-all on random read sets (60 ... 16 000 bases, 1-17 % error in indel- and substitution-
     heavy mixes, R 0.15-0.35, up to 4 000 reads) -- the bit-vector walk, with the pre-sort prefilter stage forced on and
