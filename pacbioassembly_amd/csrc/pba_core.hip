@@ -12,53 +12,56 @@
 __global__ void __launch_bounds__(256)
 k_pack_text(const uint8_t *text, const uint64_t *text_off, const uint64_t *pk_off, const uint32_t *len, uint32_t n,
             uint64_t total_dwords, uint8_t *packed, int strict, uint32_t *bad) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_dwords) return;
-    const uint64_t byte = t * 4;
-    uint32_t lo = 0, hi = n;            // last s with pk_off[s] <= byte
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (pk_off[mid] <= byte) lo = mid; else hi = mid;
+    // (grid-stride: a launch's global size is 32 bits -- a thread per dword of a 37 GB set would not fit; see elem_grid)
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_dwords; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t byte = t * 4;
+        uint32_t lo = 0, hi = n;            // last s with pk_off[s] <= byte
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pk_off[mid] <= byte) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo;
+        const uint32_t L = len[s];
+        const uint64_t w = (byte - pk_off[s]) >> 2;          // dword index inside the sequence
+        if (w * 16 >= L) continue;                           // alignment padding
+        const uint8_t *src = text + text_off[s] + w * 16;
+        const uint32_t nb = (uint32_t)min((uint64_t)16, (uint64_t)L - w * 16);
+        uint32_t word = 0, notacgt = 0;
+        for (uint32_t k = 0; k < nb; ++k) {
+            const uint32_t ch = src[k];
+            const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;   // C2I, dna_seq.h:21
+            notacgt |= (code == 3u && ch != 'T');
+            word |= code << (8 * (k >> 2) + 6 - 2 * (k & 3));   // byte k/4, first base in bits 7:6
+        }
+        *reinterpret_cast<uint32_t *>(packed + byte) = word;    // padding bytes of the last dword stay 0
+        if (notacgt) atomicOr(bad, 1u);
     }
-    const uint32_t s = lo;
-    const uint32_t L = len[s];
-    const uint64_t w = (byte - pk_off[s]) >> 2;          // dword index inside the sequence
-    if (w * 16 >= L) return;                             // alignment padding
-    const uint8_t *src = text + text_off[s] + w * 16;
-    const uint32_t nb = (uint32_t)min((uint64_t)16, (uint64_t)L - w * 16);
-    uint32_t word = 0, notacgt = 0;
-    for (uint32_t k = 0; k < nb; ++k) {
-        const uint32_t ch = src[k];
-        const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;   // C2I, dna_seq.h:21
-        notacgt |= (code == 3u && ch != 'T');
-        word |= code << (8 * (k >> 2) + 6 - 2 * (k & 3));   // byte k/4, first base in bits 7:6
-    }
-    *reinterpret_cast<uint32_t *>(packed + byte) = word;    // padding bytes of the last dword stay 0
-    if (notacgt) atomicOr(bad, 1u);
 }
 
 // Bit planes of a packed set (dev_common.h: SeqSetDev::plane): thread w owns plane word w of the whole set.
 __global__ void __launch_bounds__(256)
 k_make_planes(const uint8_t *packed, const uint64_t *off, const uint32_t *len, const uint64_t *poff, uint32_t n,
               uint64_t total_words, uint32_t *plane) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= total_words) return;
-    uint32_t lo = 0, hi = n;            // last s with poff[s] <= w
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (poff[mid] <= w) lo = mid; else hi = mid;
+    // (grid-stride: ten million 15 kb reads are 4.7 G plane words, more than a launch's 32-bit global size holds -- a thread per
+    // word silently ran the first 2^32-th of them only, tools/rehearse_config4.py; see elem_grid)
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = n;            // last s with poff[s] <= w
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (poff[mid] <= w) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo;
+        const uint64_t k = w - poff[s];     // word index inside the sequence
+        const uint32_t L = len[s];
+        uint32_t plo = 0, phi = 0;
+        if (k * 32 < L) {
+            planes_from_packed(packed + off[s], (int)(k * 32), plo, phi);
+            const uint32_t valid = L - (uint32_t)(k * 32);
+            if (valid < 32) { plo &= (1u << valid) - 1u; phi &= (1u << valid) - 1u; }   // nothing of the neighbour's bytes
+        }
+        plane[2 * w] = plo;                  // the two planes side by side: one line serves both (align_bitvec.h: load_planes32)
+        plane[2 * w + 1] = phi;
     }
-    const uint32_t s = lo;
-    const uint64_t k = w - poff[s];     // word index inside the sequence
-    const uint32_t L = len[s];
-    uint32_t plo = 0, phi = 0;
-    if (k * 32 < L) {
-        planes_from_packed(packed + off[s], (int)(k * 32), plo, phi);
-        const uint32_t valid = L - (uint32_t)(k * 32);
-        if (valid < 32) { plo &= (1u << valid) - 1u; phi &= (1u << valid) - 1u; }   // nothing of the neighbour's bytes
-    }
-    plane[2 * w] = plo;                  // the two planes side by side: one line serves both (align_bitvec.h: load_planes32)
-    plane[2 * w + 1] = phi;
 }
 
 
@@ -166,7 +169,7 @@ int pba_ctx_device_info(const pba_ctx *ctx, char *name, size_t cap, int *n_cu, i
 static int seqs_alloc(pba_ctx *ctx, pba_seqs *s, uint64_t packed_bytes) {
     s->packed_bytes = packed_bytes;
     HIPCHK(hipMalloc((void **)&s->d_alloc, packed_bytes + 2 * kSlack));
-    HIPCHK(hipMemsetAsync(s->d_alloc, 0, packed_bytes + 2 * kSlack, ctx->stream));
+    HIPCHK(memset_big(s->d_alloc, 0, packed_bytes + 2 * kSlack, ctx->stream));
     s->d_packed = s->d_alloc + kSlack;
     HIPCHK(hipMalloc((void **)&s->d_off, sizeof(uint64_t) * (s->n + 1)));
     HIPCHK(hipMalloc((void **)&s->d_len, sizeof(uint32_t) * (s->n + 1)));
@@ -183,13 +186,11 @@ static int seqs_planes(pba_ctx *ctx, pba_seqs *s) {
     poff[s->n] = w;
     s->plane_words = w + 2 * kPlaneSlack;
     HIPCHK(hipMalloc((void **)&s->d_planes, s->plane_words * 2 * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(s->d_planes, 0, s->plane_words * 2 * sizeof(uint32_t), ctx->stream));
+    HIPCHK(memset_big(s->d_planes, 0, s->plane_words * 2 * sizeof(uint32_t), ctx->stream));
     HIPCHK(hipMalloc((void **)&s->d_poff, sizeof(uint64_t) * (s->n + 1)));
     HIPCHK(hipMemcpyAsync(s->d_poff, poff.data(), sizeof(uint64_t) * (s->n + 1), hipMemcpyHostToDevice, ctx->stream));
     if (w) {
-        const uint64_t blocks = (w + 255) / 256;
-        if (blocks > 0x7FFFFFFFull) PBA_FAIL(PBA_E_TOOLONG, "sequence set too large");
-        hipLaunchKernelGGL(k_make_planes, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, s->d_packed, s->d_off, s->d_len,
+        hipLaunchKernelGGL(k_make_planes, dim3(elem_grid(w, 256)), dim3(256), 0, ctx->stream, s->d_packed, s->d_off, s->d_len,
                            s->d_poff, s->n, w, s->d_planes + 2 * kPlaneSlack);
         HIPCHK(hipGetLastError());
     }
@@ -236,9 +237,7 @@ static int seqs_pack(pba_ctx *ctx, const uint8_t *d_text, const uint64_t *d_toff
     (void)hipMemcpyAsync(s->d_off + n, &s->h_off[n], sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
     const uint64_t total_dwords = pk / 4;
     if (total_dwords) {
-        const uint64_t blocks = (total_dwords + 255) / 256;
-        if (blocks > 0x7FFFFFFFull) { pba_seqs_destroy(s); PBA_FAIL(PBA_E_TOOLONG, "sequence set too large"); }
-        hipLaunchKernelGGL(k_pack_text, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_text, d_toff, s->d_off,
+        hipLaunchKernelGGL(k_pack_text, dim3(elem_grid(total_dwords, 256)), dim3(256), 0, ctx->stream, d_text, d_toff, s->d_off,
                            s->d_len, n, total_dwords, s->d_packed, strict, bad.as<uint32_t>());
     }
     uint32_t h_bad = 0;
@@ -327,7 +326,7 @@ int pba_seqs_export(pba_ctx *ctx, const pba_seqs *s, void *d_dst, uint64_t cap, 
     if (!ctx || !s || !offsets || (!d_dst && s->packed_bytes)) return PBA_E_INVALID;
     if (cap < s->packed_bytes) PBA_FAIL(PBA_E_INVALID, "pba_seqs_export: buffer smaller than pba_seqs_packed_bytes");
     HIPCHK(hipSetDevice(ctx->device));
-    if (s->packed_bytes) HIPCHK(hipMemcpyAsync(d_dst, s->d_packed, s->packed_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (s->packed_bytes) HIPCHK(copy_d2d(d_dst, s->d_packed, s->packed_bytes, ctx->stream));
     for (uint32_t i = 0; i < s->n; ++i) offsets[i] = s->h_off[i];
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PBA_OK;
@@ -354,7 +353,7 @@ int pba_seqs_from_device_packed(pba_ctx *ctx, const void *d_packed, uint64_t n_b
     if (e == hipSuccess) e = hipMemsetAsync(s->d_alloc, 0, kSlack, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->d_alloc + kSlack + n_bytes, 0, kSlack, ctx->stream);
     if (e == hipSuccess) s->d_packed = s->d_alloc + kSlack;
-    if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(s->d_packed, d_packed, n_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && n_bytes) e = copy_d2d(s->d_packed, d_packed, n_bytes, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_off, sizeof(uint64_t) * ((size_t)n + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_len, sizeof(uint32_t) * ((size_t)n + 1));
     if (e == hipSuccess) e = hipMemcpyAsync(s->d_off, s->h_off.data(), sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream);

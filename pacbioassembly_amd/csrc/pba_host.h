@@ -141,6 +141,34 @@ struct BufRef {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// A device-to-device copy of any size: in pieces of 1 GiB.  (One hipMemcpyAsync of 37.6 GB -- the packed reads of BASELINE
+// configs[4] -- copied only the size modulo 2^32 on ROCm 7.2: tools/rehearse_config4.py found the reads beyond the first
+// 3.2 GB missing; tests/test_gpu_parity.py: test_packed_set_beyond_4_gib.)
+static inline hipError_t copy_d2d(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    const size_t piece = (size_t)1 << 30;
+    for (size_t at = 0; at < bytes; at += piece) {
+        const hipError_t e = hipMemcpyAsync((uint8_t *)dst + at, (const uint8_t *)src + at, std::min(piece, bytes - at), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+// ... and a memset likewise
+static inline hipError_t memset_big(void *dst, int v, size_t bytes, hipStream_t stream) {
+    const size_t piece = (size_t)1 << 30;
+    for (size_t at = 0; at < bytes; at += piece) {
+        const hipError_t e = hipMemsetAsync((uint8_t *)dst + at, v, std::min(piece, bytes - at), stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// Workgroups for a kernel that walks n elements with a grid-stride loop: one element per thread up to 2^30 threads.  (A
+// launch's global size -- workgroups x threads -- is a 32-bit number; a launch asking for more does not fail, it runs a part.)
+static inline uint32_t elem_grid(uint64_t n, uint32_t threads) {
+    const uint64_t blocks = (n + threads - 1) / threads, cap = ((uint64_t)1 << 30) / threads;
+    return (uint32_t)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+
 // RAII for temporaries so early returns do not leak device memory
 struct DevBuf {
     void *p = nullptr;

@@ -798,6 +798,50 @@ def test_read_shards_exported_and_regathered_give_the_same_overlaps(ctx):
     assert e.value.status == -1
 
 
+@pytest.mark.parametrize("n", [1_250_000, 9_300_000])
+def test_packed_set_beyond_4_gib(ctx, n):
+    """A sequence set over more than 4 GiB of packed bytes handed over on the device (what pba_seqs_from_device_packed gets
+    after the packed-read all-gather of BASELINE configs[4]: 37.6 GB), at two sizes: 4.7 GB, and 35 GB = 4.36 G plane words,
+    more than a kernel launch's 32-bit global size.  Every read is the bytes it was given, first to last -- its packed bases
+    (get_text), and its BIT PLANES, which is what the aligning kernels read: a read of the big set against the same text
+    uploaded on its own aligns at cost 0 on the bit-vector array.  (tools/rehearse_config4.py found both: a device-to-device
+    copy of that size goes in pieces of 1 GiB now, and the plane builder walks its words with a grid-stride loop -- a thread
+    per word silently built the planes of the first 141 000 reads only, and nine overlaps in ten went missing.)"""
+    import torch
+    rl = 15000
+    pk = ((rl + 3) // 4 + 15) & ~15
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    buf = torch.empty(n * pk, dtype=torch.uint8, device="cuda")
+    for lo in range(0, n * pk, 1 << 30):                          # (random bytes are random bases)
+        buf[lo:lo + (1 << 30)] = torch.randint(0, 256, (min(1 << 30, n * pk - lo),), dtype=torch.uint8, device="cuda", generator=g)
+    torch.cuda.synchronize()                                      # (the engine runs on its own stream)
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(pk)
+    S = ctx.seqs_from_device_packed(buf.data_ptr(), buf.numel(), offs, np.full(n, rl, np.uint32))
+    assert S.count == n and S.packed_bytes == n * pk
+
+    def text_of(i):                                               # dna_seq.h:147-159: first base in bits 7:6
+        b = buf[i * pk:i * pk + (rl + 3) // 4].cpu().numpy()
+        codes = np.stack([(b >> 6) & 3, (b >> 4) & 3, (b >> 2) & 3, b & 3], 1).reshape(-1)[:rl]
+        return np.frombuffer(b"ACGT", np.uint8)[codes].tobytes()
+    ids = [0, 1, n // 4, 141_000, 1_142_322, 1_142_323, n - 2, n - 1]      # (read 1 142 322 straddles byte 2^32)
+    texts = [text_of(i) for i in ids]
+    for i, t in zip(ids, texts):
+        assert S.get_text(i) == t, i
+    small = ctx.seqs_from_list(texts, strict_acgt=True)           # the same reads with planes of their own
+    pairs = np.array([(i, 0, rl, k, 0, rl, 0) for k, i in enumerate(ids)], PAIR_DTYPE)
+    res = ctx.align_batch(S, small, pairs, 0.3, kernel=PBA_KERNEL_BITVEC)
+    assert [(int(r["rc"]), int(r["cost"])) for r in res] == [(rl, 0)] * len(ids), res
+    small.close()
+    if n < 2_000_000:                                             # ... and back out through pba_seqs_export
+        back = torch.zeros(n * pk, dtype=torch.uint8, device="cuda")
+        o = S.export(back.data_ptr(), back.numel())
+        assert (o == offs).all()
+        for lo in (0, (1 << 32) - 4096, n * pk - 8192):
+            assert torch.equal(back[lo:lo + 8192], buf[lo:lo + 8192]), lo
+    S.close()
+
+
 def test_overlap_many_target_ranges_and_the_limits_of_a_call(ctx, oracle, monkeypatch):
     """BASELINE config 5's way through the engine at a size a test can afford: 200 000 short reads, ONE probe table, the
     targets in 25 ranges -- same overlaps and the same number of pairs as one call over everything, the oracle's
