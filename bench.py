@@ -285,7 +285,9 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
     elapsed = float(allt[:, 0].max())
     visited = n * (min(rl - 16, 20000) + max(0, min(rl - 20016, 20000)))
     scan_s = float(allt[:, 2].max())
-    scan_bytes = visited * 0.25 + counts[2] * 8
+    # (tools/bench_overlap.py: 0.25 B of packed bases + 8 B of bucket offsets per visited position, 16 B of probe record per
+    # candidate; the listed candidates' 8 B each are below 1 % of it)
+    scan_bytes = visited * 8.25 + counts[2] * 16
     return {
         "workload": f"all-vs-all overlap (BASELINE configs[3] shape), {n} x {rl} reads @15%, {a.coverage}x coverage, R={a.R}, "
                     f"{trials} probe offsets per end, targets sharded over {world} GPU(s)",
@@ -298,10 +300,11 @@ def overlap_leg(a, ctx, rank, world, nthreads, steps, warmup):
         "per_rank": {"scan_s": [round(float(x), 4) for x in allt[:, 2]], "sort_s": [round(float(x), 4) for x in allt[:, 3]],
                      "walk_s": [round(float(x), 4) for x in allt[:, 4]], "table_s": [round(float(x), 4) for x in allt[:, 5]],
                      "generate_s": [round(float(x), 2) for x in allt[:, 6]], "pack_s": [round(float(x), 2) for x in allt[:, 7]]},
-        "roofline_scan": {"bound": "hbm", "kernel": "k_ovl_count + k_ovl_fill", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
+        "roofline_scan": {"bound": "hbm", "kernel": "k_ovl_scan", "unit": "GB/s", "peak": HBM_PEAK / 1e9,
                           "achieved": round(scan_bytes / world / scan_s / 1e9, 1) if scan_s > 0 else None,
                           "frac": round(scan_bytes / world / scan_s / HBM_PEAK, 5) if scan_s > 0 else None,
-                          "note": "per GPU: 0.25 B per visited position + 8 B per candidate written, over the slowest rank's scan time"},
+                          "note": "per GPU: 8.25 B per visited position + 16 B per candidate (its probe record), over the slowest rank's scan "
+                                  "time; every candidate's first 32 rows run in the same kernel, only survivors are written"},
     }
 
 

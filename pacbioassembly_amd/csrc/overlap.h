@@ -343,10 +343,13 @@ struct OvlCfg {
 // Before this form the scan wrote all 57 G candidates of a million reads (8 B each), a second pass fetched each with one
 // scattered 64-byte line of its query to do these 32 rows, and two more passes packed the 4 % worth keeping: scan + packing
 // + sort 2.57 s of a 5.4 s run; each false candidate now costs its share of one coalesced record line and ~9 instructions.
+#ifndef PBA_SCAN_OCC
+#define PBA_SCAN_OCC 1            // waves per SIMD the register allocator must leave room for (tuning hook)
+#endif
 template <bool HASHED>
-static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES)
+static __global__ void __launch_bounds__(PBA_WAVE * PBA_OVL_WAVES, PBA_SCAN_OCC)
 k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t t_stride, const uint32_t *surv_off, uint64_t *surv, uint32_t slice_cap,
-           uint32_t *needed, OvlCfg cfg, PreThresholds pre_t, unsigned long long *totals) {
+           uint32_t *needed, OvlCfg cfg, PreChecks pre_c, unsigned long long *totals) {
     PBA_OVL_RUN_LISTS(HASHED);
     __shared__ uint32_t r_mark[PBA_OVL_WAVES][2];
     __shared__ uint32_t cursor, s_cand, s_ok;
@@ -423,14 +426,26 @@ k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t t_stride, const uin
                 const int hit = ht.pos_of((int)ord);
                 const int r_off = fwd ? hit : hit + 15;                  // spaced_seed.cpp:285
                 const int r_len = fwd ? len - r_off : r_off + 1;         // ref_seq.h:284-285
-                AlnOut po;
-                int fr = 0;
-                if (prefilter32_applies(ok, r_len, s_len, cfg.R, 0, 0, po)) {
-                    uint32_t alo, ahi;
-                    load_planes32(tf.at(r_off, fwd ? 1 : -1), 0, alo, ahi);          // rows: the target from its hit (its planes are in LDS)
-                    fr = prefilter32_planes(alo, ahi, rec.z, rec.w, pre_t);          // columns: the probe's record
+                bool failed = false;
+                // (the prefilter applies when both clipped lengths reach 32, prefilter32_applies: with max_dst >= 1 that is
+                // r_len >= 32 and s_len >= 32, seq_aligner.h:94-102)
+                if (ok && r_len >= PBA_PRE_ROWS && s_len >= PBA_PRE_ROWS) {
+                    // rows: the target's 32 elements from its hit, out of its planes in LDS (load_planes32, written out so that
+                    // the direction is a select at the end: left to itself the compiler made two copies of everything below,
+                    // one per direction, and a wavefront with both directions in it ran both)
+                    const int idx = fwd ? r_off : r_off - 31;             // lowest base index of the 32, in memory order
+                    const uint32_t *pp = s_planes + 2 * (idx >> 5);
+                    const uint32_t sh = (uint32_t)idx & 31u;
+                    const uint32_t lo32 = __builtin_amdgcn_alignbit(pp[2], pp[0], sh), hi32 = __builtin_amdgcn_alignbit(pp[3], pp[1], sh);
+                    const uint32_t rlo = __builtin_bitreverse32(lo32), rhi = __builtin_bitreverse32(hi32);
+                    const uint32_t alo = fwd ? lo32 : rlo, ahi = fwd ? hi32 : rhi;
+#ifdef PBA_SCAN_NOPRE                                                                 // (timing experiment: what the scan costs without its 32 rows)
+                    failed = ((alo ^ rec.z) & (ahi ^ rec.w)) != 0x12345u;
+#else
+                    failed = prefilter32_fails(alo, ahi, rec.z, rec.w, pre_c);       // columns: the probe's record
+#endif
                 }
-                const bool survivor = ok && fr == 0;
+                const bool survivor = ok && !failed;
                 ncand += valid; nok += ok;
                 const uint64_t sm = __builtin_amdgcn_ballot_w64(survivor);
                 if (sm) {

@@ -242,7 +242,7 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
         }
         if (const char *e = getenv("PBA_OVL_ROOM"))              // test hook: this much room for every target of every range (and so the overflow path at will)
             if (atoi(e) > 0) room = (uint32_t)atoi(e);
-        const PreThresholds pre_t = PreThresholds::on_host(R);
+        const PreChecks pre_t = PreChecks::on_host(R);
         const size_t plane_lds = sizeof(uint32_t) * 2 * ((size_t)reads->max_len / 32 + 2);     // the target's bit planes (k_ovl_scan)
         auto scan = [&](bool write, uint32_t cap_slots, uint32_t grid, uint32_t stride) -> int {
             HIPCHK(hipMemsetAsync(d_cnt64.as<unsigned long long>() + 4, 0, 16, ctx->stream));

@@ -74,6 +74,65 @@ __device__ __forceinline__ int prefilter32_planes(uint32_t alo, uint32_t ahi, ui
     return fr;
 }
 
+// The same 32 rows when only the VERDICT is wanted (the all-vs-all scan: a candidate either survives or is counted) -- and it is
+// wanted 57 G times per million reads, so every instruction of the column shows up in the scan's time:
+//  * the diagonal is not scored column by column: the D0 bit of cell (k+1, k+1) is put aside (one op), and afterwards
+//    D(i,i) = i - popcount of the first i of those bits;
+//  * D(i,i) never decreases with i, and floor(i*R) is constant over stretches of rows, so a stretch fails iff its LAST row
+//    fails: only those rows are checked (7 of the 22 at R = 0.30; PreChecks::rows, formed on the host);
+//  * the column's logic in v_bitop3_b32 forms (three inputs, any truth table, full rate): 16 vector ops per column, 4 of them
+//    at the half rate of shifts and bit-field extracts, where the scoring form has ~23.
+// Same cells, same FP64-derived thresholds, same verdict (every all-vs-all test holds it against the row-sweep kernel, which
+// has no prefilter).
+struct PreChecks {
+    PreThresholds t;
+    uint32_t rows;                  // bit i-1: row i (11..32) is the last of a stretch of equal thresholds -- check it
+    static PreChecks on_host(double R) {
+        PreChecks c;
+        c.t = PreThresholds::on_host(R);
+        c.rows = 0;
+        auto T = [&](int i) { return (int)((c.t.p[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
+        for (int i = 11; i <= PBA_PRE_ROWS; ++i)
+            if (i == PBA_PRE_ROWS || T(i + 1) != T(i)) c.rows |= 1u << (i - 1);
+        return c;
+    }
+};
+// (a ^ b) | c,  a | ~(b | c)
+__device__ __forceinline__ uint32_t bitop_xor_or(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xbe" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // (0xF0 ^ 0xCC) | 0xAA
+    return d;
+}
+__device__ __forceinline__ uint32_t bitop_or_nor(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xf1" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // 0xF0 | ~(0xCC | 0xAA)
+    return d;
+}
+// true: some row 11..32 fails the reference's check (seq_aligner.h:185)
+__device__ __forceinline__ bool prefilter32_fails(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, const PreChecks &C) {
+    uint32_t Pv = ~0u, Mv = 0u, diag = 0u;     // column 0: D(i,0) = i;  diag bit k: D(k+1, k+1) == D(k, k)
+#pragma unroll
+    for (int k = 0; k < PBA_PRE_ROWS; ++k) {
+        const uint32_t clo = bit_mask(blo, k), chi = bit_mask(bhi, k);
+        const uint32_t Eq = eq_mask(alo ^ clo, ahi, chi);                 // ~(alo ^ clo) & ~(ahi ^ chi)
+        const uint32_t Xh = bitop_xor_or((Eq & Pv) + Pv, Pv, Eq);         // (((Eq & Pv) + Pv) ^ Pv) | Eq
+        const uint32_t Xv = Eq | Mv;
+        uint32_t Ph = bitop_or_nor(Mv, Xh, Pv);                           // Mv | ~(Xh | Pv)
+        uint32_t Mh = Pv & Xh;
+        diag |= (Xh | Mv) & (1u << k);                                    // D0 of the diagonal cell
+        Ph = (Ph << 1) | 1u;                                              // row 0 grows by one per column: D(0,j) = j
+        Mh <<= 1;
+        Pv = bitop_or_nor(Mh, Xv, Ph);                                    // Mh | ~(Xv | Ph)
+        Mv = Ph & Xv;
+    }
+    bool fail = false;
+#pragma unroll
+    for (int i = 11; i <= PBA_PRE_ROWS; ++i)
+        if ((C.rows >> (i - 1)) & 1u)                                     // (wave-uniform: a kernel argument)
+            fail = fail || i - (int)__builtin_popcount(i == 32 ? diag : diag & ((1u << i) - 1u)) > C.t.at(i);
+    return fail;
+}
+
 // whether the prefilter applies to a pair of these accessor lengths (else the full aligner decides)
 __device__ __forceinline__ bool prefilter32_applies(bool active, int la, int lb, double R, int maxn, int maxm, AlnOut &o) {
     aln_params(la, lb, R, o);

@@ -34,16 +34,30 @@ for rep in range(max(1, a.reps)):              # (the first pass of a process al
     if best is None or dt < best[0]:
         best = (dt, st)
 dt, st = best
-# scan roofline: algorithmic bytes = 0.25 B per visited position (the packed bases, read once) + 8 B per
-# candidate written; the scan makes two passes over the positions (slice sizes, then the candidates)
-visited = sum(min(a.read_len - 16, 20000) + max(0, min(a.read_len - 20016, 20000)) for _ in range(1)) * a.reads
-scan_bytes = visited * 0.25 + st["n_candidates"] * 8
-scan_gbs = scan_bytes / (st["scan_ms"] * 1e-3) / 1e9 if st["scan_ms"] > 0 else 0.0
+# rooflines of the stages.  Scan (k_ovl_scan, HBM): algorithmic bytes = 0.25 B per visited position (the packed
+# bases, read once) + 8 B per visited position for its bucket's offset pair + 16 B per candidate (its probe record, read) + 8 B
+# per listed candidate (written).  Sort (k_seg_sort, HBM): 16 B per listed candidate (read + written).  The walk is integer
+# issue work like k_locate: overlaps/s and listed candidates/s are its figures.
+visited = (min(a.read_len - 16, 20000) + max(0, min(a.read_len - 20016, 20000))) * a.reads
+listed = int(st.get("n_listed", 0))
+scan_bytes = visited * 8.25 + st["n_candidates"] * 16 + listed * 8
+scan_s, sort_s, walk_s = st["scan_ms"] * 1e-3, st["sort_ms"] * 1e-3, st["walk_ms"] * 1e-3
+scan_gbs = scan_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+sort_gbs = listed * 16 / sort_s / 1e9 if sort_s > 0 else 0.0
 print(json.dumps({"workload": f"all-vs-all, {a.reads} x {a.read_len} reads @15%, genome {L} ({a.coverage}x), R={a.R}, {a.trials} trials/end",
-                  "seconds": round(dt, 3), "reps": a.reps, "n_prefiltered": int(st.get("n_prefiltered", 0)), "overlaps": int(st["n_overlaps"]), "pairs": int(st["n_pairs"]),
+                  "seconds": round(dt, 3), "reps": a.reps, "n_prefiltered": int(st.get("n_prefiltered", 0)), "n_listed": listed, "overlaps": int(st["n_overlaps"]), "pairs": int(st["n_pairs"]),
                   "candidates": int(st["n_candidates"]), "pairs_per_s": round(st["n_pairs"] / dt, 1),
                   "overlaps_per_s": round(st["n_overlaps"] / dt, 1), "table_ms": st["table_ms"], "scan_ms": st["scan_ms"],
                   "sort_ms": st["sort_ms"], "walk_ms": st["walk_ms"], "n_big_targets": st.get("n_big_targets", 0),
-                  "roofline_scan": {"bound": "hbm", "kernel": "k_ovl_count + k_ovl_fill", "achieved": round(scan_gbs, 1), "peak": 8000.0,
+                  "cap_fill": st.get("cap_fill", 0), "cap_overflow": st.get("cap_overflow", 0),
+                  "roofline_scan": {"bound": "hbm", "kernel": "k_ovl_scan (+ k_pt_ctx once per table)", "achieved": round(scan_gbs, 1), "peak": 8000.0,
                                     "unit": "GB/s", "frac": round(scan_gbs / 8000.0, 5), "positions": int(visited),
-                                    "algorithmic_bytes": int(scan_bytes), "positions_per_s": round(visited / (st["scan_ms"] * 1e-3), 1) if st["scan_ms"] > 0 else None}}))
+                                    "algorithmic_bytes": int(scan_bytes), "positions_per_s": round(visited / scan_s, 1) if scan_s > 0 else None,
+                                    "candidates_per_s": round(st["n_candidates"] / scan_s, 1) if scan_s > 0 else None,
+                                    "note": "8.25 B per visited position + 16 B per candidate + 8 B per listed candidate; the 32 rows of every candidate "
+                                            "(~9 wave64 instructions each) run in the same kernel"},
+                  "roofline_sort": {"bound": "hbm", "kernel": "k_seg_sort<256|1024>", "achieved": round(sort_gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                    "frac": round(sort_gbs / 8000.0, 5), "algorithmic_bytes": listed * 16,
+                                    "note": "16 B per listed candidate; at this size the stage is a few launches of latency per target range"},
+                  "walk": {"bound": "valu-issue", "kernel": "k_ovl_walk<NB> cascade + k_ovl_after", "overlaps_per_s": round(st["n_overlaps"] / walk_s, 1) if walk_s > 0 else None,
+                           "listed_per_s": round(listed / walk_s, 1) if walk_s > 0 else None}}))
