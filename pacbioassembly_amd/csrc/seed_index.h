@@ -23,11 +23,17 @@
 #include "dev_common.h"
 
 #define PBA_IX_MAX_LOGP 24                 // partitions of ~2 048 entries for up to 2^32 entries (minus the average)
-#define PBA_IX_LVL_BITS 8                  // hash bits one partition level resolves (256 bins: two u32 LDS tables = 2 KB)
+#ifndef PBA_IX_LVL_BITS
+#define PBA_IX_LVL_BITS 8                  // hash bits one partition level resolves (256 bins: two u32 LDS tables = 2 KB); tuning hook
+#endif
+#ifndef PBA_IX_PART_AVG
 #define PBA_IX_PART_AVG 2048               // entries per partition the builder aims at (1 024 .. 2 048)
+#endif
 #define PBA_IX_LDS_SORT_CAP 16384          // entries of the largest segment one k_seg_sort workgroup takes (1 024 threads x 16)
 #define PBA_IX_TILE_THREADS 256
+#ifndef PBA_IX_TILE_ITERS
 #define PBA_IX_TILE_ITERS 4
+#endif
 #define PBA_IX_TILE_POS (PBA_IX_TILE_THREADS * 16 * PBA_IX_TILE_ITERS)   // positions per workgroup
 
 struct IndexDev {
