@@ -84,16 +84,21 @@ __device__ __forceinline__ int prefilter32_planes(uint32_t alo, uint32_t ahi, ui
 //    at the half rate of shifts and bit-field extracts, where the scoring form has ~23.
 // Same cells, same FP64-derived thresholds, same verdict (every all-vs-all test holds it against the row-sweep kernel, which
 // has no prefilter).
+// rows the scan sweeps (<= 32; tuning hook).  Fewer rows cost less per candidate and let more candidates through to the walk,
+// whose own stage (rows 1..64 of every listed candidate) is exact whatever got here: measured at a million reads, §5.1
+#ifndef PBA_SCAN_ROWS
+#define PBA_SCAN_ROWS 32
+#endif
 struct PreChecks {
     PreThresholds t;
-    uint32_t rows;                  // bit i-1: row i (11..32) is the last of a stretch of equal thresholds -- check it
+    uint32_t rows;                  // bit i-1: row i (11..PBA_SCAN_ROWS) is the last of a stretch of equal thresholds -- check it
     static PreChecks on_host(double R) {
         PreChecks c;
         c.t = PreThresholds::on_host(R);
         c.rows = 0;
         auto T = [&](int i) { return (int)((c.t.p[i >> 2] >> (8 * (i & 3))) & 0xFFu); };
-        for (int i = 11; i <= PBA_PRE_ROWS; ++i)
-            if (i == PBA_PRE_ROWS || T(i + 1) != T(i)) c.rows |= 1u << (i - 1);
+        for (int i = 11; i <= PBA_SCAN_ROWS; ++i)
+            if (i == PBA_SCAN_ROWS || T(i + 1) != T(i)) c.rows |= 1u << (i - 1);
         return c;
     }
 };
@@ -112,7 +117,7 @@ __device__ __forceinline__ uint32_t bitop_or_nor(uint32_t a, uint32_t b, uint32_
 __device__ __forceinline__ bool prefilter32_fails(uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi, const PreChecks &C) {
     uint32_t Pv = ~0u, Mv = 0u, diag = 0u;     // column 0: D(i,0) = i;  diag bit k: D(k+1, k+1) == D(k, k)
 #pragma unroll
-    for (int k = 0; k < PBA_PRE_ROWS; ++k) {
+    for (int k = 0; k < PBA_SCAN_ROWS; ++k) {                             // (cell (i,i), i <= PBA_SCAN_ROWS, needs columns 1..i only)
         const uint32_t clo = bit_mask(blo, k), chi = bit_mask(bhi, k);
         const uint32_t Eq = eq_mask(alo ^ clo, ahi, chi);                 // ~(alo ^ clo) & ~(ahi ^ chi)
         const uint32_t Xh = bitop_xor_or((Eq & Pv) + Pv, Pv, Eq);         // (((Eq & Pv) + Pv) ^ Pv) | Eq
@@ -127,7 +132,7 @@ __device__ __forceinline__ bool prefilter32_fails(uint32_t alo, uint32_t ahi, ui
     }
     bool fail = false;
 #pragma unroll
-    for (int i = 11; i <= PBA_PRE_ROWS; ++i)
+    for (int i = 11; i <= PBA_SCAN_ROWS; ++i)
         if ((C.rows >> (i - 1)) & 1u)                                     // (wave-uniform: a kernel argument)
             fail = fail || i - (int)__builtin_popcount(i == 32 ? diag : diag & ((1u << i) - 1u)) > C.t.at(i);
     return fail;
