@@ -1434,6 +1434,35 @@ def test_overlap_later_ranges_of_a_table_skip_the_count_pass(ctx, monkeypatch):
         assert (st["cap_fill"] + st["cap_overflow"] > 0) == bool(n_cap) and (st["cap_overflow"] > 0) == bool(n_over), (pct, st)
 
 
+@pytest.mark.parametrize("pattern", ["1111111111111111", "111111111111111*", "1111111*11111111"])
+def test_overlap_all_heavy_masks_hashed_table(ctx, oracle, pattern, prekeep):
+    """Masks with more than 26 care bits: the probe table is a 2^26-bucket hash with the probes' keys stored beside them
+    (overlap.h: HASHED) -- a bucket can hold probes of other keys, which the scan must skip.  300 reads at 3 % error (whole
+    16-mers have to match): the bit-vector form against the row-sweep form, and both against the oracle's locked rounds."""
+    g = eng.synth_genome(611, 60000)
+    n, rl = 300, 2500
+    reads, offs, _ = eng.synth_reads(612, g, n, rl, 0.01, 0.01, 0.01)
+    texts = [reads[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(n)]
+    file = b"".join(eng.text2bin(t) for t in texts)
+    rec_offs = np.cumsum([0] + [4 + (len(t) + 3) // 4 for t in texts[:-1]]).astype(np.uint64)
+    mask = eng.mask_from_pattern(pattern)
+    assert bin(mask).count("1") > 26
+    S = ctx.seqs_from_list(texts, strict_acgt=True)
+    want, wst = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_ROWSWEEP)
+    got, st = ctx.overlap_all(S, mask, 0.30, 32, 64, kernel=PBA_KERNEL_BITVEC)
+    assert len(want) > 1500 and (got == want).all()
+    assert st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"] and st["n_probe_entries"] == wst["n_probe_entries"]
+    pairs = 0
+    for t in (0, 7, 150, n - 1):
+        rows = oracle.spaced_round(texts[t], mask, 0.30, file, rec_offs, 32, 64, buggy=False, nthreads=8)
+        exp = [(t, q, int(rows["j"][q]), int(rows["dir"][q]), int(rows["ref_pos"][q]), int(rows["cost"][q]), int(rows["matlen_a"][q]),
+                int(rows["matlen_b"][q])) for q in np.nonzero(rows["found"])[0] if q != t]
+        lo, hi = np.searchsorted(got["target"], [t, t + 1])
+        assert [tuple(int(x) for x in r) for r in got[lo:hi]] == exp and len(exp) >= 3, t
+        one, st1 = ctx.overlap_all(S, mask, 0.30, 32, 64, t_lo=t, t_hi=t + 1)
+        assert st1["n_pairs"] == int(rows["n_pairs"].sum()) - int(rows["n_pairs"][t]), t
+
+
 def test_overlap_15kb_reads_sampled_targets_vs_oracle(ctx, oracle, monkeypatch):
     """BASELINE configs[3]'s read shape at a size the oracle can spot-check: 2 400 x 15 kb reads @15 % at 20 x coverage through
     ONE probe table in three target ranges -- sampled census, equal-room slices from the second range on, the scan's 32 rows,
