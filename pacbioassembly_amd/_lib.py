@@ -135,7 +135,41 @@ SYMBOLS = {
     "pba_strerror": (C.c_char_p, [C.c_int]),
 }
 
+# include/pba_dist.h (libpba_dist.so: the exchange over RCCL for C / C++ hosts)
+DIST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libpba_dist.so")
+DIST_SYMBOLS = {
+    "pba_dist_unique_id": (C.c_int, [_P]),
+    "pba_dist_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "pba_dist_comm_destroy": (None, [_P]),
+    "pba_dist_rank": (C.c_int, [_P]),
+    "pba_dist_world": (C.c_int, [_P]),
+    "pba_dist_shard": (None, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "pba_dist_all_gather": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "pba_dist_all_reduce_u64": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
+    "pba_dist_index_build": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "pba_dist_gather_reads": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "pba_dist_probe_table": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+}
+
 _lib = None
+_dist = None
+
+
+def load_dist() -> C.CDLL:
+    """Load libpba_dist.so (after libpba.so, so that both bind the HIP runtime and the RCCL torch has mapped)."""
+    global _dist
+    if _dist is not None:
+        return _dist
+    load()
+    if not os.path.exists(DIST_LIB_PATH):
+        raise RuntimeError(f"{DIST_LIB_PATH} is missing: build it with `python -m pacbioassembly_amd.build`")
+    lib = C.CDLL(DIST_LIB_PATH)
+    for name, (res, args) in DIST_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _dist = lib
+    return lib
 
 
 def load() -> C.CDLL:

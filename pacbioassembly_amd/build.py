@@ -23,6 +23,9 @@ LIB = os.path.join(LIBDIR, "libpba.so")
 
 SOURCES = ["pba_core.hip", "pba_align.hip", "pba_drivers.hip", "pba_overlap.hip", "pba_cons.hip", "pba_codec.cpp",
            "pba_synth.cpp"]
+# the exchange over RCCL for C / C++ hosts (include/pba_dist.h): host code only, its own small library next to libpba.so
+DIST_SOURCE = "pba_dist.hip"
+DIST_LIB = os.path.join(LIBDIR, "libpba_dist.so")
 
 
 def _hipcc() -> str:
@@ -58,6 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(p) for p in srcs + _headers()) \
             and not os.environ.get("PBA_EXTRA_CFLAGS"):
+        build_dist()
         return LIB                      # (the objects do not travel to the GPU box; the library does)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc, flags = _hipcc(), _flags()
@@ -84,7 +88,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", LIB] + objs + ["-lpthread"])
         open(stamp, "w").write(flag_text)
+    build_dist(verbose=verbose)
     return LIB
+
+
+def build_dist(force: bool = False, verbose: bool = False) -> str:
+    """libpba_dist.so: pba_dist.hip against libpba.so and librccl.so (found beside libpba.so through $ORIGIN)."""
+    src = os.path.join(CSRC, DIST_SOURCE)
+    deps = [src, LIB] + _headers() + [os.path.join(ROOT, "include", "pba_dist.h")]
+    if not force and os.path.exists(DIST_LIB) and os.path.getmtime(DIST_LIB) >= max(os.path.getmtime(p) for p in deps):
+        return DIST_LIB
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+    cmd = [_hipcc()] + _flags() + ["-shared", "-o", DIST_LIB, src, "-L", LIBDIR, "-lpba", "-L", rocm_lib, "-lrccl",
+                                   "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return DIST_LIB
 
 
 if __name__ == "__main__":

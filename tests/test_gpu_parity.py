@@ -1522,6 +1522,71 @@ def test_overlap_repeats_outgrow_one_sort_with_and_without_the_pre_sort_stage():
     assert r.stdout.count(" same ") == 2 and "big targets 142" in r.stdout
 
 
+def test_c_level_exchange_over_rccl_world_of_one(ctx, lib, tmp_path):
+    """include/pba_dist.h (libpba_dist.so): the multi-GPU exchange as C entry points over RCCL, for hosts that are not Python.
+    A box with one GPU can run a world of one -- RCCL itself wants a GPU per rank -- which still goes through every call:
+    communicator bring-up from a unique id, the collectives, and the three composite steps, each against its single-process
+    counterpart: pba_dist_index_build == pba_index_build, pba_dist_gather_reads gives the set back read for read,
+    pba_dist_probe_table + pba_overlap_all_table == pba_overlap_all.  Then examples/overlap_dist.cpp (plain g++ over the two
+    headers) prints the same totals.  (More ranks: tests/dist_overlap_worker.py runs the same protocol over gloo.)"""
+    import ctypes as C
+    import os
+    import subprocess
+    import torch
+    from conftest import ROOT
+    from pacbioassembly_amd import _lib, ProbeTable
+    from pacbioassembly_amd.engine import SeqSet, SeedIndex
+    dl = _lib.load_dist()
+    ident = (C.c_uint8 * 128)()
+    assert dl.pba_dist_unique_id(ident) == 0
+    comm = C.c_void_p()
+    assert dl.pba_dist_comm_create(ctx.h, 0, 1, ident, C.byref(comm)) == 0, ctx.lib.pba_ctx_error(ctx.h)
+    assert dl.pba_dist_rank(comm) == 0 and dl.pba_dist_world(comm) == 1
+    vals = (C.c_uint64 * 3)(5, 7, 9)
+    assert dl.pba_dist_all_reduce_u64(comm, vals, 3, 0) == 0 and list(vals) == [5, 7, 9]
+    a = torch.arange(4096, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    assert dl.pba_dist_all_gather(comm, C.c_void_p(a.data_ptr()), 4096, C.c_void_p(b.data_ptr())) == 0 and torch.equal(a, b)
+    # the seed index built "by all ranks" == the single-process build
+    g = eng.synth_genome(901, 300000)
+    mask = eng.mask_from_pattern(MASK_PAT)
+    T = ctx.seqs_from_list([g.tobytes()], strict_acgt=True)
+    for mode in (PBA_INDEX_ALL, PBA_INDEX_HEAD_TAIL):
+        h = C.c_void_p()
+        assert dl.pba_dist_index_build(comm, T.h, 0, mask, mode, C.byref(h)) == 0, ctx.lib.pba_ctx_error(ctx.h)
+        ix2, ix1 = SeedIndex(ctx, h), ctx.index_build(T, 0, mask, mode)
+        (k1, p1), (k2, p2) = ix1.dump(), ix2.dump()
+        assert ix1.entries == ix2.entries > 30000 and (k1 == k2).all() and (p1 == p2).all()
+    # the read set from "the ranks' shards", the probe table from "the ranks' probes": the all-vs-all is the single-process one
+    n, rl = 600, 1500
+    genome = eng.synth_genome(2, n * rl // 20)
+    reads, offs = eng.synth_reads_range(3, genome, 0, n, rl)
+    mine = ctx.seqs_from_text(reads, offs, strict_acgt=True)
+    h = C.c_void_p()
+    assert dl.pba_dist_gather_reads(comm, mine.h, C.byref(h)) == 0, ctx.lib.pba_ctx_error(ctx.h)
+    allr = SeqSet(ctx, h)
+    assert allr.count == n and all(allr.get_text(i) == mine.get_text(i) for i in (0, 1, 299, n - 1))
+    th = C.c_void_p()
+    assert dl.pba_dist_probe_table(comm, allr.h, 0, n, mask, 32, C.byref(th)) == 0, ctx.lib.pba_ctx_error(ctx.h)
+    table = ProbeTable.__new__(ProbeTable)
+    table.ctx, table.h = ctx, th
+    got, st = ctx.overlap_all_table(allr, table, 0.30, 64)
+    want, wst = ctx.overlap_all(mine, mask, 0.30, 32, 64)
+    assert len(want) > 1000 and (got == want).all() and st["n_pairs"] == wst["n_pairs"] and st["n_candidates"] == wst["n_candidates"]
+    table.close()
+    dl.pba_dist_comm_destroy(comm)
+    # the same from C++
+    libdir = os.path.join(ROOT, "pacbioassembly_amd", "lib")
+    exe = str(tmp_path / "overlap_dist")
+    subprocess.run(["g++", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "examples", "overlap_dist.cpp"),
+                    "-L", libdir, "-lpba_dist", "-lpba", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib"], check=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([exe, str(n), str(rl)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"all ranks: {wst['n_pairs']} candidate pairs, {wst['n_overlaps']} overlaps" in r.stdout, r.stdout
+
+
 def test_bench_two_ranks_share_the_gpu_and_agree_with_one(lib):
     """The N > 1 paths of bench.py on the GPU box there is: two ranks (started by bench.py's own launcher) share the one GPU
     and exchange over gloo instead of RCCL (which needs a GPU per rank) -- seed-index exchange and locate in weak scaling,
