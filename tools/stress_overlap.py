@@ -37,14 +37,15 @@ for rnd in range(a.rounds):
     S = ctx.seqs_from_list(texts, strict_acgt=True)
     mask = eng.mask_from_pattern(masks[rnd % len(masks)])
     R = float(rng.choice([0.15, 0.25, 0.30, 0.35]))
-    trials = int(rng.choice([8, 32]))
+    trials = int(rng.choice([8, 32, 63]))
+    omin = int(rng.choice([16, 64, 64, 200]))                      # OVERLAP_MIN (spaced_seed.cpp:280, ref_seq.h:265): below / at / above the prefilter's 32 rows
     os.environ.pop("PBA_OVL_ROOM", None)
-    want, wst = ctx.overlap_all(S, mask, R, trials, 64, kernel=PBA_KERNEL_ROWSWEEP)
-    line = f"round {rnd}: {n} reads x {rl} @ {e:.2f} ({mix[0]:.3f}/{mix[1]:.3f}/{mix[2]:.3f}) cov {cov:.0f} R {R} trials {trials}: " \
+    want, wst = ctx.overlap_all(S, mask, R, trials, omin, kernel=PBA_KERNEL_ROWSWEEP)
+    line = f"round {rnd}: {n} reads x {rl} @ {e:.2f} ({mix[0]:.3f}/{mix[1]:.3f}/{mix[2]:.3f}) cov {cov:.0f} R {R} trials {trials} min {omin}: " \
            f"{len(want)} overlaps, {wst['n_pairs']} pairs, {wst['n_candidates']} candidates"
     for mode in ("0", "8"):                                        # census + exact slices; equal room that overflows and is redone
         os.environ["PBA_OVL_ROOM"] = mode
-        got, st = ctx.overlap_all(S, mask, R, trials, 64, kernel=PBA_KERNEL_BITVEC)
+        got, st = ctx.overlap_all(S, mask, R, trials, omin, kernel=PBA_KERNEL_BITVEC)
         ok = (got.size == want.size and (got == want).all() and st["n_pairs"] == wst["n_pairs"]
               and st["n_candidates"] == wst["n_candidates"])
         line += f" | room {mode}: {'same' if ok else 'DIFFERENT'} (redo {st['n_redo']}, prefiltered {st['n_prefiltered']}, overflow {st['cap_overflow']})"
