@@ -365,7 +365,6 @@ k_ovl_scan(ProbeTab T, SeqSetDev Rd, uint32_t t_lo, uint32_t t_stride, const uin
         for (int k = (int)threadIdx.x; k < nw; k += PBA_WAVE * PBA_OVL_WAVES) s_planes[k] = gp[k];
     }
     __syncthreads();
-    const PackedFetch tf{seq, 0, 1, s_planes};
     const TargetWalk tw(len);
     const HeadTail ht(len);
     uint64_t *out = surv_off ? surv + surv_off[tl] : nullptr;

@@ -28,12 +28,16 @@ extern "C" {
 // the probe table of a read set (overlap.h: ProbeTab), built once and scanned by every target range
 struct pba_probe_table {
     int device;
-    ProbeTab T;
+    mutable ProbeTab T;            // (prec is attached on first use)
     bool hashed;
     uint32_t t2;
     uint64_t n_entries;
     float build_ms;
-    mutable const pba_seqs *rec_reads;   // the read set prec[] was filled from (nullptr: not yet -- on first use, overlap.h: k_pt_ctx)
+    // the read set prec[] was filled from (rec_reads == nullptr: not yet -- on first use, overlap.h: k_pt_ctx); a table belongs to
+    // one read set, and the arena's address and size are compared too, should a set have been replaced at the same address
+    mutable const pba_seqs *rec_reads;
+    mutable const uint8_t *rec_packed;
+    mutable uint64_t rec_bytes;
     // what a call learned from its sample about this read set under (R, ring): whether the narrow window certifies its
     // overlaps.  The next target ranges against the same table skip the sample (three launches and their tails per call).
     mutable uint32_t slice_max;    // largest / average candidate slice of a target in the last counted range of >= 1 024 targets (0: none yet)
@@ -221,13 +225,13 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     (void)hipEventRecord(ctx->ev[2], ctx->stream);
     if (fused) {
         // 1. the records of the probe table from this read set, once per table
-        if (tab->rec_reads != reads) {
-            if (!T.prec) HIPCHK(hipMalloc((void **)&const_cast<ProbeTab &>(T).prec, sizeof(uint4) * ((uint64_t)tab->n_entries + 1)));
+        if (tab->rec_reads != reads || tab->rec_packed != reads->d_packed || tab->rec_bytes != reads->packed_bytes) {
+            if (!tab->T.prec) HIPCHK(hipMalloc((void **)&tab->T.prec, sizeof(uint4) * ((uint64_t)tab->n_entries + 1)));
             if (tab->n_entries)
                 hipLaunchKernelGGL(k_pt_ctx, dim3((uint32_t)((tab->n_entries + 255) / 256)), dim3(256), 0, ctx->stream, T, reads->dev(),
                                    (uint32_t)tab->n_entries);
             HIPCHK(hipGetLastError());
-            tab->rec_reads = reads;
+            tab->rec_reads = reads; tab->rec_packed = reads->d_packed; tab->rec_bytes = reads->packed_bytes;
         }
         // 2. the scan.  How much room a target's survivors need is not known before its candidates have been through their
         //    32 rows: the first range of a table runs the scan once without writing (needed[] only) and then with exact
@@ -500,6 +504,9 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     const size_t n_all = (size_t)n_items64;
     size_t sample_min = 4096;
     if (const char *e = getenv("PBA_OVL_SAMPLE_MIN")) sample_min = (size_t)std::max(1L, atol(e));   // test hook: small inputs through the sampled decision
+    if (const char *e = getenv("PBA_OVL_WIDE")) {                // tuning hook: 0 / 1 = start every range narrow / in the wider ring, no sample
+        tab->wide_known = atoi(e) != 0 ? 1 : 0; tab->wide_R = R; tab->wide_nb1 = pl.nb1;
+    }
     const bool decided = tab->wide_known >= 0 && tab->wide_R == R && tab->wide_nb1 == pl.nb1 && !getenv("PBA_OVL_SAMPLE_MIN");
     const size_t n_sample = pl.nb1 == 0 ? n_all : (decided ? 0 : std::min(n_all, std::max<size_t>(sample_min, n_all / 32)));
     uint64_t parked = 0;

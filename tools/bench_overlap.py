@@ -49,7 +49,7 @@ print(json.dumps({"workload": f"all-vs-all, {a.reads} x {a.read_len} reads @15%,
                   "candidates": int(st["n_candidates"]), "pairs_per_s": round(st["n_pairs"] / dt, 1),
                   "overlaps_per_s": round(st["n_overlaps"] / dt, 1), "table_ms": st["table_ms"], "scan_ms": st["scan_ms"],
                   "sort_ms": st["sort_ms"], "walk_ms": st["walk_ms"], "n_big_targets": st.get("n_big_targets", 0),
-                  "cap_fill": st.get("cap_fill", 0), "cap_overflow": st.get("cap_overflow", 0),
+                  "cap_fill": st.get("cap_fill", 0), "cap_overflow": st.get("cap_overflow", 0), "n_redo": int(st.get("n_redo", 0)), "wide_first": int(st.get("wide_first", 0)),
                   "roofline_scan": {"bound": "hbm", "kernel": "k_ovl_scan (+ k_pt_ctx once per table)", "achieved": round(scan_gbs, 1), "peak": 8000.0,
                                     "unit": "GB/s", "frac": round(scan_gbs / 8000.0, 5), "positions": int(visited),
                                     "algorithmic_bytes": int(scan_bytes), "positions_per_s": round(visited / scan_s, 1) if scan_s > 0 else None,
