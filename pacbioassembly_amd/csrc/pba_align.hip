@@ -273,17 +273,6 @@ static inline int text_guard(pba_ctx *ctx, const TextClip &c, int maxn, int maxm
 // elements are the bytes [p-(len-1), p] and the accessor's origin is the last of them
 static inline const uint8_t *acc_low(const char *p, int fwd, int len) { return (const uint8_t *)((fwd || len == 0) ? p : p - (len - 1)); }
 
-static inline int stage_reserve(pba_ctx *ctx, size_t bytes) {
-    if (ctx->h_stage_cap >= bytes) return PBA_OK;
-    if (ctx->h_stage) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_cap = 0; }
-    const size_t want = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError(); ctx->h_stage = nullptr;
-        PBA_FAIL(PBA_E_NOMEM, "pinned staging buffer");
-    }
-    ctx->h_stage_cap = want;
-    return PBA_OK;
-}
 static inline int scratch_reserve(pba_ctx *ctx, size_t need) {
     if (need <= ctx->scratch_bytes) return PBA_OK;
     if (ctx->d_scratch) { HIPCHK(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_scratch); }

@@ -92,6 +92,7 @@ int pba_ctx_create(int device_id, pba_ctx **out) {
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < 6; ++i)
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PBA_E_HIP; }
+    if (hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) { delete ctx; return PBA_E_HIP; }
     memset(&ctx->prof, 0, sizeof ctx->prof);
     if (hipMalloc((void **)&ctx->d_queue, 64) != hipSuccess) { delete ctx; return PBA_E_NOMEM; }
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
@@ -110,6 +111,7 @@ void pba_ctx_destroy(pba_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->own_stream);
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipEventDestroy(ctx->ev_aux);
     (void)hipFree(ctx->d_queue);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     for (auto &b : ctx->pool) if (b.p) (void)hipFree(b.p);
@@ -465,10 +467,12 @@ static VisitPlan visit_plan(uint32_t len, int mode) {
     return v;
 }
 
-static uint32_t seg_grid(const ScanSeg &sg) {
+static uint32_t seg_grid(const ScanSeg &sg, int iters = PBA_IX_TILE_ITERS) {
     const uint64_t chunks = ((uint64_t)sg.hi + 15) / 16 - sg.lo / 16;
-    return (uint32_t)((chunks + PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS - 1) / (PBA_IX_TILE_THREADS * PBA_IX_TILE_ITERS));
+    return (uint32_t)((chunks + PBA_IX_TILE_THREADS * iters - 1) / (PBA_IX_TILE_THREADS * iters));
 }
+// small inputs: tiles of 4 096 entries (one chunk per thread) instead of 16 384 -- a 5 Mb target is 305 big tiles on 256 CUs
+static bool index_small_tiles(uint64_t n_upper) { return n_upper <= (32ull << 20); }
 
 // partitions of 1 024 .. 2 048 entries on average
 static int index_logp(uint64_t n) {
@@ -488,14 +492,20 @@ static pba_index *index_new(pba_ctx *ctx, uint32_t mask, uint32_t len, int mode,
 }
 
 // in-place inclusive scan of a[0 .. n) on the stream (seed_index.h: k_scan_*); tiles: scratch of n / PBA_SCAN_TILE + 1 u32
-static void scan_inclusive(pba_ctx *ctx, uint32_t *a, uint64_t n, uint32_t *tiles) {
+// shifted (nullable): see k_scan_small; true when it was written (else the caller copies)
+static bool scan_inclusive(pba_ctx *ctx, uint32_t *a, uint64_t n, uint32_t *tiles, uint32_t *shifted = nullptr) {
+    if (n && n <= PBA_SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, a, (uint32_t)n, shifted);
+        return shifted != nullptr;
+    }
     const uint32_t n_tiles = (uint32_t)((n + PBA_SCAN_TILE - 1) / PBA_SCAN_TILE);
-    if (!n_tiles) return;
+    if (!n_tiles) return false;
     hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(256), 0, ctx->stream, a, n, tiles);
     if (n_tiles > 1) {
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, tiles, n_tiles);
         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(256), 0, ctx->stream, a, n, tiles);
     }
+    return false;
 }
 
 // The partition levels and the sort.  n_upper: an upper bound of the entries (positions visited / slots of the gathered
@@ -504,6 +514,7 @@ static void scan_inclusive(pba_ctx *ctx, uint32_t *a, uint64_t n, uint32_t *tile
 // through the generic level kernels on this flat list (all-ones entries = padding).
 static int index_levels(pba_ctx *ctx, pba_index *ix, uint64_t n_upper, const uint64_t *from_list,
                         const std::function<void(int, uint32_t *, uint32_t *, uint64_t *)> &level1) {
+    const uint32_t tile = index_small_tiles(n_upper) ? 4096u : (uint32_t)PBA_IX_TILE_POS;
     if (n_upper > 0xFFFFFFF0ull) PBA_FAIL(PBA_E_TOOLONG, "more than 2^32 index entries");
     ix->logP = index_logp(n_upper);
     const int logP = ix->logP, n_levels = std::max(1, (logP + PBA_IX_LVL_BITS - 1) / PBA_IX_LVL_BITS);
@@ -528,56 +539,68 @@ static int index_levels(pba_ctx *ctx, pba_index *ix, uint64_t n_upper, const uin
     struct Spare { pba_ctx *ctx; void **p; size_t *cap; ~Spare() {          // the buffer the index does not keep: back to the cache
         if (*p) { if (!ctx->ix_cache.ent2) { ctx->ix_cache.ent2 = *p; ctx->ix_cache.ent2_cap = *cap; } else (void)hipFree(*p); }
     } } spare{ctx, &second, &second_cap};
-    POOL(POOL_IX_OFFS, sizeof(uint32_t) * (2 * P + 2 * (uint64_t)n_levels + 8), offs.p);             // sum over the levels < 2 P + levels
+    // offsets of every level (sum over the levels < 2 P + levels), {0, n} of a gathered list, then what the build wants zero
+    // at its start beside them -- [zero_at]: largest partition, partitions beyond the LDS sort, entries; the sort's oversize
+    // list -- all zeroed by ONE memset (a fill per array and level was 30 us of a 330 us build at 5 Mb)
+    const uint32_t ov_cap = (uint32_t)std::min<uint64_t>(P, 4096);
+    const uint64_t offs_words = 2 * P + 2 * (uint64_t)n_levels + 8, zero_at = offs_words, all_words = offs_words + 4 + 1 + ov_cap;
+    POOL(POOL_IX_OFFS, sizeof(uint32_t) * all_words, offs.p);
+    HIPCHK(hipMemsetAsync(offs.p, 0, sizeof(uint32_t) * all_words, ctx->stream));
+    uint32_t *const stat = offs.as<uint32_t>() + zero_at, *const ov = stat + 4;
     POOL(POOL_IX_WORK, sizeof(uint32_t) * (3 * P + 64), work.p);                                     // cursor | tile_pre | scan scratch
     uint32_t *const cursor = work.as<uint32_t>(), *const tile_pre = cursor + P + 8, *const tiles = tile_pre + P + 8;
     uint32_t *off_prev = nullptr, *off_k = offs.as<uint32_t>();
     uint32_t *const list_off = offs.as<uint32_t>() + 2 * P + 2 * (uint64_t)n_levels + 4;    // {0, n}: the one group of a gathered list
     int done = 0, cur = 0;
+    sta = stage_reserve(ctx, 64);
+    if (sta != PBA_OK) return sta;
+    uint32_t *const h_stat = (uint32_t *)ctx->h_stage;                             // pinned (read after the event below): [0] largest partition <= the LDS sort's cap, [1] partitions beyond it, [2] entries
     (void)hipEventRecord(ctx->ev[0], ctx->stream);
     for (int k = 0; k < n_levels; ++k) {
         const int bits = (logP - done + (n_levels - k) - 1) / (n_levels - k);      // the remaining bits, split evenly
         const uint64_t bins = 1ull << (done + bits);
-        HIPCHK(hipMemsetAsync(off_k, 0, sizeof(uint32_t) * (bins + 1), ctx->stream));
         LvlSrc L;
         uint32_t grid = 0;
         if (k > 0 || from_list) {
             // tiles of the groups: tile_pre[g] = tiles of the groups before g
             L.src = k == 0 ? from_list : (const uint64_t *)ent[cur ^ 1]; L.done = done; L.bits = bits;
-            L.n_groups = (uint32_t)(1ull << done);
+            L.n_groups = (uint32_t)(1ull << done); L.tile = tile;
             if (k == 0) {                                                          // one group: the whole list
-                const uint32_t h[2] = {0u, (uint32_t)n_upper}, t[2] = {0u, (uint32_t)((n_upper + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS)};
+                const uint32_t h[2] = {0u, (uint32_t)n_upper}, t[2] = {0u, (uint32_t)((n_upper + tile - 1) / tile)};
                 HIPCHK(hipMemcpyAsync(list_off, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
                 HIPCHK(hipMemcpyAsync(tile_pre, t, sizeof t, hipMemcpyHostToDevice, ctx->stream));
                 HIPCHK(hipStreamSynchronize(ctx->stream));                         // (h, t are locals)
                 L.off_prev = list_off;
             } else {
-                HIPCHK(hipMemsetAsync(tile_pre, 0, sizeof(uint32_t), ctx->stream));
-                hipLaunchKernelGGL(k_lvl_tiles, dim3((L.n_groups + 255) / 256), dim3(256), 0, ctx->stream, off_prev, L.n_groups, tile_pre + 1);
+                hipLaunchKernelGGL(k_lvl_tiles, dim3((L.n_groups + 255) / 256), dim3(256), 0, ctx->stream, off_prev, L.n_groups, tile, tile_pre + 1);
                 scan_inclusive(ctx, tile_pre + 1, L.n_groups, tiles);
                 L.off_prev = off_prev;
             }
             L.tile_pre = tile_pre;
-            grid = (uint32_t)(n_upper / PBA_IX_TILE_POS + L.n_groups + 1);          // >= the tiles there are; the rest exit
+            grid = (uint32_t)(n_upper / tile + L.n_groups + 1);                     // >= the tiles there are; the rest exit
         }
         if (grid) hipLaunchKernelGGL(k_lvl_count, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, L, off_k + 1);
         else level1(bits, off_k + 1, nullptr, nullptr);
-        scan_inclusive(ctx, off_k + 1, bins, tiles);
-        HIPCHK(hipMemcpyAsync(cursor, off_k, sizeof(uint32_t) * bins, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!scan_inclusive(ctx, off_k + 1, bins, tiles, cursor))
+            HIPCHK(hipMemcpyAsync(cursor, off_k, sizeof(uint32_t) * bins, hipMemcpyDeviceToDevice, ctx->stream));
+        if (k == n_levels - 1) {
+            // The partitions' sizes are final once the last level has been counted: the totals the host decides by (entries,
+            // the largest partition the LDS sort takes, partitions beyond it) are queued for the host BEFORE the last scatter
+            // and read while it runs -- the sort is launched without the chip waiting for a host round trip (75 us of a
+            // 330 us build at 5 Mb).
+            hipLaunchKernelGGL(k_part_max, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, ctx->stream, off_k, (uint32_t)P, stat);
+            HIPCHK(hipMemcpyAsync(h_stat, stat, 12, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipEventRecord(ctx->ev_aux, ctx->stream));
+        }
         if (grid) hipLaunchKernelGGL(k_lvl_scatter, dim3(grid), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, L, cursor, (uint64_t *)ent[cur]);
         else level1(bits, nullptr, cursor, (uint64_t *)ent[cur]);
         off_prev = off_k; off_k += bins + 1; done += bits; cur ^= 1;
     }
     cur ^= 1;                                                                      // the buffer the last level wrote
-    // totals: entries, the largest partition the LDS sort takes, partitions beyond it
-    uint32_t *const stat = tiles;                                                  // (the scan scratch is free again)
-    HIPCHK(hipMemsetAsync(stat, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_part_max, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, ctx->stream, off_prev, (uint32_t)P, stat);
-    uint32_t h_stat[2] = {0, 0}, total = 0;
-    HIPCHK(hipMemcpyAsync(h_stat, stat, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&total, off_prev + P, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // totals: entries, the largest partition the LDS sort takes, partitions beyond it (queued before the last scatter)
+    HIPCHK(hipEventSynchronize(ctx->ev_aux));
     HIPCHK(hipGetLastError());
+    const uint32_t total = h_stat[2];
     ix->n_entries = total;
     sta = ix_alloc(ctx, &ctx->ix_cache.off, &ctx->ix_cache.off_cap, sizeof(uint32_t) * (P + 1), (void **)&ix->d_part_off, &ix->off_cap);
     if (sta != PBA_OK) return sta;
@@ -588,9 +611,6 @@ static int index_levels(pba_ctx *ctx, pba_index *ix, uint64_t n_upper, const uin
         // every partition sorted by key, then insertion order: k_seg_sort (buckets by the key's gathered care bits, sorted in
         // wavefront registers); what it leaves -- partitions beyond 16 384 entries or with a bucket beyond 256: low-complexity
         // targets -- goes through the global bitonic pass
-        const uint32_t ov_cap = (uint32_t)std::min<uint64_t>(P, 4096);
-        uint32_t *const ov = tile_pre;                                             // (free again: 1 + ov_cap <= P + 8 slots)
-        HIPCHK(hipMemsetAsync(ov, 0, sizeof(uint32_t), ctx->stream));
         launch_seg_sort(ctx, ix->d_ent, ix->d_ent, ix->d_part_off, nullptr, P, std::max(h_stat[0], h_stat[1] ? 0xFFFFFFFFu : 0u),
                         seg_bkt_key(ix->mask), ov, ov_cap);
         std::vector<uint32_t> h_ov(1 + ov_cap, 0);
@@ -634,10 +654,12 @@ int pba_index_build(pba_ctx *ctx, const pba_seqs *target, uint32_t seq, uint32_t
     for (int s = 0; s < v.nseg; ++s) npos += v.segs[s].hi - v.segs[s].lo;
     const uint8_t *d_seq = target->d_packed + target->h_off[seq];
     int st = index_levels(ctx, ix, npos, nullptr, [&](int bits, uint32_t *cnt1, uint32_t *cursor, uint64_t *dst) {
+        // (level 1 keeps its tiles of 16 384 positions at any size: with 4 096 the per-bin reservations of four times the
+        // workgroups cost more than the idle CUs -- 13 -> 26 us and 35 -> 43 us at 5 Mb)
         for (int s = 0; s < v.nseg; ++s) {
-            if (!dst) hipLaunchKernelGGL(k_seed_count, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+            if (!dst) hipLaunchKernelGGL(k_seed_count<PBA_IX_TILE_ITERS>, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
                                          mask, v.segs[s], bits, cnt1);
-            else hipLaunchKernelGGL(k_seed_scatter, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
+            else hipLaunchKernelGGL(k_seed_scatter<PBA_IX_TILE_ITERS>, dim3(seg_grid(v.segs[s])), dim3(PBA_IX_TILE_THREADS), 0, ctx->stream, d_seq, len,
                                     mask, v.segs[s], bits, cursor, dst);
         }
     });

@@ -40,6 +40,7 @@ struct pba_ctx {
     hipStream_t own_stream, stream;
     hipDeviceProp_t prop;
     hipEvent_t ev[6];        // index begin/end, align begin/end, redo begin/end
+    hipEvent_t ev_aux;       // "the small D2H copy queued before the last kernel has landed" (index build: sizes before the last scatter)
     uint32_t *d_queue;       // work-queue counters of the persistent aligning kernels (one per launch in flight)
     void *d_scratch;         // parent-bit scratch of the trace / vote kernels, kept between calls (tens of GB: mapping
     size_t scratch_bytes;    // it anew on every call cost seconds); grown on demand, freed with the ctx
@@ -169,6 +170,20 @@ static inline uint32_t elem_grid(uint64_t n, uint32_t threads) {
     return (uint32_t)std::max<uint64_t>(1, std::min(blocks, cap));
 }
 
+// the ctx's pinned host staging buffer, at least `bytes` (one H2D / D2H copy per call of the one-pair text entry points; small
+// results a host decision waits for)
+static inline int stage_reserve(pba_ctx *ctx, size_t bytes) {
+    if (ctx->h_stage_cap >= bytes) return PBA_OK;
+    if (ctx->h_stage) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); ctx->h_stage = nullptr;
+        return ctx_fail(ctx, PBA_E_NOMEM, "pinned staging buffer", hipSuccess);
+    }
+    ctx->h_stage_cap = want;
+    return PBA_OK;
+}
+
 // RAII for temporaries so early returns do not leak device memory
 struct DevBuf {
     void *p = nullptr;
@@ -259,15 +274,18 @@ static inline SegBkt seg_bkt_key(uint32_t mask) {
 // oversize[1 ..] for the caller's global pass; oversize[0] must be zero on entry)
 static inline void launch_seg_sort(pba_ctx *ctx, const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const SegRef *segs,
                                    uint64_t n_seg, uint32_t max_n, const SegBkt &bk, uint32_t *oversize, uint32_t oversize_cap) {
-    for (uint64_t s0 = 0; s0 < n_seg; s0 += 0x40000000ull) {
-        const uint32_t g = (uint32_t)std::min<uint64_t>(n_seg - s0, 0x40000000ull);
-        // (oversize ids are relative to the launch: only one launch unless there are more than 2^30 segments)
-        if (max_n <= 256 * PBA_SS_EPT)
+    // (a launch's global size -- workgroups x threads -- is a 32-bit number: at most 2^21 segments of 1 024 threads, 2^23 of 256,
+    // per launch; seg_off / segs are addressed from the launch's first segment, reports carry the global index)
+    const bool small = max_n <= 256 * PBA_SS_EPT;
+    const uint64_t per = small ? (1ull << 23) : (1ull << 21);
+    for (uint64_t s0 = 0; s0 < n_seg; s0 += per) {
+        const uint32_t g = (uint32_t)std::min<uint64_t>(n_seg - s0, per);
+        if (small)
             hipLaunchKernelGGL(k_seg_sort<256>, dim3(g), dim3(256), 0, ctx->stream, src, dst, seg_off ? seg_off + s0 : nullptr,
-                               segs ? segs + s0 : nullptr, bk, oversize, oversize_cap);
+                               segs ? segs + s0 : nullptr, bk, oversize, oversize_cap, (uint32_t)s0);
         else
             hipLaunchKernelGGL(k_seg_sort<1024>, dim3(g), dim3(1024), 0, ctx->stream, src, dst, seg_off ? seg_off + s0 : nullptr,
-                               segs ? segs + s0 : nullptr, bk, oversize, oversize_cap);
+                               segs ? segs + s0 : nullptr, bk, oversize, oversize_cap, (uint32_t)s0);
     }
 }
 

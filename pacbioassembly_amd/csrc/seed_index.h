@@ -27,7 +27,7 @@
 #define PBA_IX_LVL_BITS 8                  // hash bits one partition level resolves (256 bins: two u32 LDS tables = 2 KB); tuning hook
 #endif
 #ifndef PBA_IX_PART_AVG
-#define PBA_IX_PART_AVG 2048               // entries per partition the builder aims at (1 024 .. 2 048)
+#define PBA_IX_PART_AVG 2048               // entries per partition the builder aims at (1 024 .. 2 048); tuning hook
 #endif
 #define PBA_IX_LDS_SORT_CAP 16384          // entries of the largest segment one k_seg_sort workgroup takes (1 024 threads x 16)
 #define PBA_IX_TILE_THREADS 256
@@ -111,6 +111,9 @@ __device__ __forceinline__ uint32_t chunk_key(uint64_t be, uint32_t k, uint32_t 
 
 // level 1 from the packed bases: bin = the top `bits` bits of the key's hash
 // cnt1 points one slot past the bin's offset slot (counts are scanned in place into offsets)
+// ITERS: chunks of 16 positions a thread takes (a workgroup's tile = 256 x 16 x ITERS positions): PBA_IX_TILE_ITERS, or 1 for
+// inputs so small that tiles of 16 384 would leave most of the chip without a workgroup (a 5 Mb target is 305 of them)
+template <int ITERS>
 static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int bits, uint32_t *cnt1) {
     __shared__ uint32_t hist[1 << PBA_IX_LVL_BITS];
@@ -118,8 +121,8 @@ k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int bi
     for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
     __syncthreads();
     const uint32_t chunk0 = sg.lo >> 4;
-    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
-        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+    for (int it = 0; it < ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
         if ((uint64_t)chunk * 16 >= sg.hi) break;
         const uint64_t be = chunk_bits(seq, chunk);
 #pragma unroll
@@ -136,6 +139,7 @@ k_seed_count(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int bi
 }
 
 // ... and the entries into their level-1 bins (order inside a bin does not matter: the partitions are sorted at the end)
+template <int ITERS>
 static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int bits, uint32_t *cursor, uint64_t *dst) {
     __shared__ uint32_t hist[1 << PBA_IX_LVL_BITS];
@@ -144,9 +148,9 @@ k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int 
     for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) hist[p] = 0;
     __syncthreads();
     const uint32_t chunk0 = sg.lo >> 4;
-    uint64_t be[PBA_IX_TILE_ITERS];
-    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
-        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+    uint64_t be[ITERS];
+    for (int it = 0; it < ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
         be[it] = 0;
         if ((uint64_t)chunk * 16 >= sg.hi) continue;
         be[it] = chunk_bits(seq, chunk);
@@ -165,8 +169,8 @@ k_seed_scatter(const uint8_t *seq, uint32_t len, uint32_t mask, ScanSeg sg, int 
         hist[p] = 0;
     }
     __syncthreads();
-    for (int it = 0; it < PBA_IX_TILE_ITERS; ++it) {
-        const uint32_t chunk = chunk0 + (blockIdx.x * PBA_IX_TILE_ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
+    for (int it = 0; it < ITERS; ++it) {
+        const uint32_t chunk = chunk0 + (blockIdx.x * ITERS + it) * PBA_IX_TILE_THREADS + threadIdx.x;
         if ((uint64_t)chunk * 16 >= sg.hi) continue;
 #pragma unroll
         for (uint32_t k = 0; k < 16; ++k) {
@@ -190,6 +194,7 @@ struct LvlSrc {
     const uint32_t *off_prev, *tile_pre;
     uint32_t n_groups;
     int done, bits;
+    uint32_t tile;           // entries of a tile: PBA_IX_TILE_POS, or 4 096 for small inputs (more workgroups; still >= 64 entries per bin at 6 bits)
 };
 __device__ __forceinline__ bool lvl_tile(const LvlSrc &L, uint32_t &group, uint32_t &lo, uint32_t &hi) {
     uint32_t a = 0, b = L.n_groups;                     // last group g with tile_pre[g] <= blockIdx.x
@@ -199,8 +204,8 @@ __device__ __forceinline__ bool lvl_tile(const LvlSrc &L, uint32_t &group, uint3
         if (L.tile_pre[mid] <= blockIdx.x) a = mid; else b = mid;
     }
     group = a;
-    lo = L.off_prev[a] + (blockIdx.x - L.tile_pre[a]) * PBA_IX_TILE_POS;
-    hi = min(L.off_prev[a + 1], lo + (uint32_t)PBA_IX_TILE_POS);
+    lo = L.off_prev[a] + (blockIdx.x - L.tile_pre[a]) * L.tile;
+    hi = min(L.off_prev[a + 1], lo + L.tile);
     return true;
 }
 // the entry's bin inside its group: the `bits` hash bits below the top `done`
@@ -208,9 +213,10 @@ __device__ __forceinline__ uint32_t lvl_bin(const LvlSrc &L, uint64_t e) {
     return L.bits ? ((((uint32_t)(e >> 32)) * 0x9E3779B1u) >> (32 - L.done - L.bits)) & ((1u << L.bits) - 1u) : 0u;
 }
 static __global__ void __launch_bounds__(256)
-k_lvl_tiles(const uint32_t *off_prev, uint32_t n_groups, uint32_t *ntiles1) {
+k_lvl_tiles(const uint32_t *off_prev, uint32_t n_groups, uint32_t tile, uint32_t *ntiles1) {   // ntiles1[-1] = 0: the scan's exclusive start
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_groups) ntiles1[g] = (off_prev[g + 1] - off_prev[g] + PBA_IX_TILE_POS - 1) / PBA_IX_TILE_POS;
+    if (g == 0) ntiles1[-1] = 0;
+    if (g < n_groups) ntiles1[g] = (off_prev[g + 1] - off_prev[g] + tile - 1) / tile;
 }
 static __global__ void __launch_bounds__(PBA_IX_TILE_THREADS)
 k_lvl_count(LvlSrc L, uint32_t *cnt1) {
@@ -257,11 +263,12 @@ k_lvl_scatter(LvlSrc L, uint32_t *cursor, uint64_t *dst) {
 }
 // the largest partition (for the LDS the sort asks for) and how many outgrow the LDS sort
 static __global__ void __launch_bounds__(256)
-k_part_max(const uint32_t *part_off, uint32_t P, uint32_t *out2) {
+k_part_max(const uint32_t *part_off, uint32_t P, uint32_t *out3) {        // out3[0..1] zero on entry; out3[2] = entries in all
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    if (p == 0) out3[2] = part_off[P];
     const uint32_t n = part_off[p + 1] - part_off[p];
-    if (n <= PBA_IX_LDS_SORT_CAP) atomicMax(&out2[0], n); else atomicAdd(&out2[1], 1u);
+    if (n <= PBA_IX_LDS_SORT_CAP) atomicMax(&out3[0], n); else atomicAdd(&out3[1], 1u);
 }
 
 // ---- multi-GPU exchange form: a rank scans its slice of the visiting order into a flat entry list ...
@@ -355,6 +362,40 @@ k_scan_sums(uint32_t *tile_sum, uint32_t n_tiles) {      // one workgroup, exclu
         __syncthreads();
     }
 }
+// ... and for up to 2^13 values one launch of one workgroup (a level's 64 .. 4 096 bin counts: three launches of ~5 us each
+// were a tenth of a 5 Mb index build).  shifted (nullable): shifted[0] = 0, shifted[i + 1] = a[i] after the scan, i + 1 < n -- the
+// cursor copy the scatter kernels consume, written here instead of by a device-to-device copy.
+#define PBA_SCAN_SMALL_MAX 8192             // (one workgroup: 4 096 values 7 us, 32 768 values 44 us -- the three launches take 15)
+static __global__ void __launch_bounds__(1024)
+k_scan_small(uint32_t *a, uint32_t n, uint32_t *shifted) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) { carry_s = 0; if (shifted) shifted[0] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t b0 = 0; b0 < n; b0 += 1024 * 8) {
+        const uint32_t base = b0 + threadIdx.x * 8;
+        uint32_t v[8], run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? a[base + k] : 0u; run += v[k]; v[k] = run; }
+        uint32_t inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t carry = carry_s + inc - run;
+        for (int k = 0; k < w; ++k) carry += wsum[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (base + k < n) {
+                a[base + k] = v[k] + carry;
+                if (shifted && base + k + 1 < n) shifted[base + k + 1] = v[k] + carry;
+            }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + run;
+        __syncthreads();
+    }
+}
 static __global__ void __launch_bounds__(256)
 k_scan_add(uint32_t *a, uint64_t n, const uint32_t *tile_pre) {
     const uint32_t c = tile_pre[blockIdx.x];
@@ -433,7 +474,7 @@ __device__ __forceinline__ void wave_sort256(uint64_t (&x)[4], int lane) {   // 
 template <int T>
 static __global__ void __launch_bounds__(T)
 k_seg_sort(const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const SegRef *segs, SegBkt bk, uint32_t *oversize,
-           uint32_t oversize_cap) {
+           uint32_t oversize_cap, uint32_t seg_base) {        // (seg_base: this launch's first segment -- what it reports is seg_base + its own index)
     __shared__ uint32_t hist[PBA_SS_MAXBKT + 2], cur[PBA_SS_MAXBKT + 2], wsum[T / PBA_WAVE];
     __shared__ unsigned long long s_min, s_max;
     const uint32_t lo = segs ? segs[blockIdx.x].off : seg_off[blockIdx.x];
@@ -441,7 +482,7 @@ k_seg_sort(const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const Se
     if (n < 2) { if (n == 1 && src != dst && threadIdx.x == 0) dst[lo] = src[lo]; return; }
     if (n > T * PBA_SS_EPT) {                                        // beyond this launch: the caller's fallback
         if (src != dst) for (uint32_t i = threadIdx.x; i < n; i += T) dst[lo + i] = src[lo + i];
-        if (threadIdx.x == 0) { const uint32_t k = atomicAdd(&oversize[0], 1u); if (k < oversize_cap) oversize[1 + k] = blockIdx.x; }
+        if (threadIdx.x == 0) { const uint32_t k = atomicAdd(&oversize[0], 1u); if (k < oversize_cap) oversize[1 + k] = seg_base + blockIdx.x; }
         return;
     }
     const int lane = threadIdx.x & (PBA_WAVE - 1), wave = threadIdx.x / PBA_WAVE;
@@ -529,7 +570,7 @@ k_seg_sort(const uint64_t *src, uint64_t *dst, const uint32_t *seg_off, const Se
     }
     if (__builtin_amdgcn_ballot_w64(too_big) && lane == 0) {
         const uint32_t k = atomicAdd(&oversize[0], 1u);
-        if (k < oversize_cap) oversize[1 + k] = blockIdx.x;
+        if (k < oversize_cap) oversize[1 + k] = seg_base + blockIdx.x;
     }
 }
 
