@@ -339,7 +339,7 @@ def _overlap_all(self, reads, mask, R, max_trial=32, overlap_min=64, t_lo=0, t_h
     """All-vs-all overlap of a read set (targets t_lo..t_hi); returns (overlaps sorted by (target, query), stats)."""
     t_hi = reads.count if t_hi is None else t_hi
     cap = cap if cap is not None else max(1, (t_hi - t_lo) * max(reads.count - 1, 1))
-    out = np.zeros(cap, OVERLAP_DTYPE)
+    out = np.empty(cap, OVERLAP_DTYPE)                 # (not zeroed: 320 MB per target range at ten million reads; rows beyond n are never handed out)
     n = C.c_uint64()
     st = _lib.PbaOverlapStats()
     self.check(self.lib.pba_overlap_all(self.h, reads.h, t_lo, t_hi, mask, R, max_trial, overlap_min, kernel, _ptr(out), cap,
@@ -359,7 +359,7 @@ def _overlap_all_probes(self, reads, d_entries_ptr, n_slots, mask, R, max_trial=
                         kernel=PBA_KERNEL_AUTO, cap=None):
     t_hi = reads.count if t_hi is None else t_hi
     cap = cap if cap is not None else max(1, (t_hi - t_lo) * max(reads.count - 1, 1))
-    out = np.zeros(cap, OVERLAP_DTYPE)
+    out = np.empty(cap, OVERLAP_DTYPE)                 # (not zeroed: 320 MB per target range at ten million reads; rows beyond n are never handed out)
     n = C.c_uint64()
     st = _lib.PbaOverlapStats()
     self.check(self.lib.pba_overlap_all_probes(self.h, reads.h, t_lo, t_hi, C.c_void_p(d_entries_ptr), n_slots, mask, R, max_trial,
@@ -391,7 +391,7 @@ class ProbeTable:
 def _overlap_all_table(self, reads, table, R, overlap_min=64, t_lo=0, t_hi=None, kernel=PBA_KERNEL_AUTO, cap=None):
     t_hi = reads.count if t_hi is None else t_hi
     cap = cap if cap is not None else max(1, (t_hi - t_lo) * max(reads.count - 1, 1))
-    out = np.zeros(cap, OVERLAP_DTYPE)
+    out = np.empty(cap, OVERLAP_DTYPE)                 # (not zeroed: 320 MB per target range at ten million reads; rows beyond n are never handed out)
     n = C.c_uint64()
     st = _lib.PbaOverlapStats()
     self.check(self.lib.pba_overlap_all_table(self.h, reads.h, t_lo, t_hi, table.h, R, overlap_min, kernel, _ptr(out), cap,
