@@ -554,9 +554,30 @@ int pba_overlap_all_table(pba_ctx *ctx, const pba_seqs *reads, uint32_t t_lo, ui
     const uint64_t got = std::min<uint64_t>(h_cnt2[0], cap);
     if (got) HIPCHK(hipMemcpyAsync(out, d_out.p, sizeof(pba_overlap) * got, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::sort(out, out + got, [](const pba_overlap &x, const pba_overlap &y) {
-        return x.target != y.target ? x.target < y.target : x.query < y.query;
-    });
+    // rows by (target, query): the walk's wavefronts emit in the order they finish.  A counting pass over the range's targets,
+    // then the few rows of a target by query (a comparison sort of the whole list was 12 ms per 200 000 rows on the host: a
+    // tenth of a 200 k-read pass)
+    if (got > 1) {
+        std::vector<uint32_t> first(nt + 1, 0);
+        bool in_range = true;
+        for (uint64_t i = 0; i < got; ++i) {
+            const uint32_t tl = (uint32_t)out[i].target - t_lo;
+            if (tl >= nt) { in_range = false; break; }
+            ++first[tl + 1];
+        }
+        if (in_range) {
+            for (uint32_t t = 0; t < nt; ++t) first[t + 1] += first[t];
+            std::vector<pba_overlap> tmp(out, out + got);
+            std::vector<uint32_t> at(first.begin(), first.end() - 1);
+            for (uint64_t i = 0; i < got; ++i) out[at[(uint32_t)tmp[i].target - t_lo]++] = tmp[i];
+            for (uint32_t t = 0; t < nt; ++t)
+                if (first[t + 1] - first[t] > 1)
+                    std::sort(out + first[t], out + first[t + 1], [](const pba_overlap &x, const pba_overlap &y) { return x.query < y.query; });
+        } else
+            std::sort(out, out + got, [](const pba_overlap &x, const pba_overlap &y) {
+                return x.target != y.target ? x.target < y.target : x.query < y.query;
+            });
+    }
     *n_out = h_cnt2[0];
     st.n_overlaps = h_cnt2[0];
     st.n_pairs = fused ? n_ok - h_after : h_cnt2[1];
